@@ -1,0 +1,216 @@
+"""gdpt_amd — MI355X-native drop-in for LaJolla's Integrator::GradPath hot path.
+
+Thin Python mirror of the reference's operator-level entry points over the C ABI in include/gdpt.h
+(libgdpt.so: host ingest in C++, kernels in HIP for gfx950). Names follow the reference:
+
+    parse_scene(path)                     src/parsers/parse_scene.h:9
+    Scene(desc) / render(...)             gradient_path_render tile loop, src/render.cpp:257-333
+    fourierSolve(w, h, c, gx, gy, alpha)  src/render.cpp:172-254
+    gradient_path_render(scene, ...)      src/render.cpp:257-370
+    imwrite(filename, image)              src/image.cpp:135-173
+
+There is no CPU fallback: every compute call goes to the HIP library and raises if it is missing
+or no GPU is visible. (The directory name contains hyphens; import it through the top-level
+`gdpt_amd.py` shim.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._ctypes_defs import *  # noqa: F401,F403
+from . import _ctypes_defs as defs
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgdpt.so")
+_LIB = None
+
+
+class GdptError(RuntimeError):
+    """Raised for a non-zero status from the C ABI (the reference throws fl_exception, src/flexception.h)."""
+
+
+def library_path():
+    return LIB_PATH
+
+
+def lib():
+    """Loads libgdpt.so; fails loudly when the HIP extension has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise GdptError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                            f"(make -C gradient-based-path-tracing_amd/csrc); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        vp = C.c_void_p
+        L.gdpt_last_error.restype = C.c_char_p
+        L.gdpt_build_arch.restype = C.c_char_p
+        L.gdpt_parse_scene.argtypes = [C.c_char_p, C.POINTER(C.POINTER(defs.GdptSceneDesc))]
+        L.gdpt_free_scene_desc.argtypes = [C.POINTER(defs.GdptSceneDesc)]
+        L.gdpt_scene_upload.argtypes = [C.POINTER(defs.GdptSceneDesc), C.c_int, C.POINTER(vp)]
+        L.gdpt_scene_free.argtypes = [vp]
+        L.gdpt_scene_info.argtypes = [vp] + [C.POINTER(C.c_int32)] * 4
+        L.gdpt_render.argtypes = [vp, C.POINTER(defs.GdptRenderParams), dp, dp, dp, dp, dp, C.POINTER(defs.GdptRenderStats)]
+        L.gdpt_render_device.argtypes = [vp, C.POINTER(defs.GdptRenderParams), vp, vp, vp, vp, vp, vp, C.POINTER(defs.GdptRenderStats)]
+        L.gdpt_assemble_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.gdpt_poisson_solve.argtypes = [C.c_int, C.c_int, dp, dp, dp, C.c_double, dp]
+        L.gdpt_poisson_solve_ex.argtypes = [C.c_int, C.c_int, dp, dp, dp, C.c_double, dp, C.c_int, C.c_double, C.c_int,
+                                            C.POINTER(defs.GdptPoissonStats)]
+        L.gdpt_poisson_solve_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, C.c_int, C.c_double, C.c_int,
+                                                vp, C.POINTER(defs.GdptPoissonStats)]
+        L.gdpt_gradient_path_render.argtypes = [vp, C.POINTER(defs.GdptRenderParams), C.c_double, dp, dp, dp, dp, dp, dp,
+                                                C.POINTER(defs.GdptRenderStats), C.POINTER(defs.GdptPoissonStats)]
+        L.gdpt_imwrite.argtypes = [C.c_char_p, C.c_int, C.c_int, dp]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise GdptError(lib().gdpt_last_error().decode("utf-8", "replace"))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class SceneDesc:
+    """Host-side flattened scene (owner of a GdptSceneDesc*), the result of parse_scene()."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    @property
+    def desc(self):
+        return self.ptr.contents
+
+    @property
+    def width(self):
+        return self.ptr.contents.camera.width
+
+    @property
+    def height(self):
+        return self.ptr.contents.camera.height
+
+    def close(self):
+        if self.ptr:
+            lib().gdpt_free_scene_desc(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def parse_scene(filename):
+    """Mitsuba-0.x XML subset -> SceneDesc (reference: parse_scene, src/parsers/parse_scene.cpp:1615-1630)."""
+    p = C.POINTER(defs.GdptSceneDesc)()
+    _check(lib().gdpt_parse_scene(os.fsencode(filename), C.byref(p)))
+    return SceneDesc(p)
+
+
+def _params(spp, rng_scheme, rows, max_depth_override=0):
+    p = defs.GdptRenderParams()
+    p.spp, p.rng_scheme = int(spp), int(rng_scheme)
+    p.row_begin, p.row_end = int(rows[0]), int(rows[1])
+    p.max_depth_override = int(max_depth_override)
+    return p
+
+
+class Scene:
+    """Device-resident scene: own BVH2 + fp32 traversal records + fp64 shading tables in HBM
+    (replaces Scene::Scene's Embree build, src/scene.cpp:4-53)."""
+
+    def __init__(self, scene_desc, device=0):
+        self.desc = scene_desc
+        self.width, self.height = scene_desc.width, scene_desc.height
+        h = C.c_void_p()
+        _check(lib().gdpt_scene_upload(scene_desc.ptr, int(device), C.byref(h)))
+        self.handle = h
+
+    def info(self):
+        v = [C.c_int32() for _ in range(4)]
+        _check(lib().gdpt_scene_info(self.handle, *[C.byref(x) for x in v]))
+        return dict(zip(("num_nodes", "num_tris", "num_spheres", "bvh_depth"), [x.value for x in v]))
+
+    def render(self, spp=0, rng_scheme=defs.RNG_SAMPLE, rows=(0, 0)):
+        """Five-buffer render to host arrays (HxWx3 float64). Returns (buffers, GdptRenderStats)."""
+        shape = (self.height, self.width, 3)
+        bufs = {k: np.zeros(shape, dtype=np.float64) for k in ("img", "cx0", "cy0", "cx1", "cy1")}
+        st = defs.GdptRenderStats()
+        p = _params(spp, rng_scheme, rows)
+        _check(lib().gdpt_render(self.handle, C.byref(p), _dp(bufs["img"]), _dp(bufs["cx0"]), _dp(bufs["cy0"]),
+                                 _dp(bufs["cx1"]), _dp(bufs["cy1"]), C.byref(st)))
+        return bufs, st
+
+    def render_device(self, ptrs, spp=0, rng_scheme=defs.RNG_SAMPLE, rows=(0, 0), stream=None, want_stats=False):
+        """Five-buffer render into device memory; `ptrs` = 5 device addresses (e.g. torch tensor.data_ptr())."""
+        st = defs.GdptRenderStats() if want_stats else None
+        p = _params(spp, rng_scheme, rows)
+        _check(lib().gdpt_render_device(self.handle, C.byref(p), *[C.c_void_p(int(x)) for x in ptrs],
+                                        C.c_void_p(int(stream) if stream else 0), C.byref(st) if st is not None else None))
+        return st
+
+    def gradient_path_render(self, spp=0, rng_scheme=defs.RNG_SAMPLE, alpha=0.04, return_buffers=False):
+        """Whole Integrator::GradPath: render + assembly + screened-Poisson solve (src/render.cpp:257-370)."""
+        shape = (self.height, self.width, 3)
+        out = np.zeros(shape, dtype=np.float64)
+        bufs = {k: np.zeros(shape, dtype=np.float64) for k in ("img", "cx0", "cy0", "cx1", "cy1")}
+        rs, ps = defs.GdptRenderStats(), defs.GdptPoissonStats()
+        p = _params(spp, rng_scheme, (0, 0))
+        _check(lib().gdpt_gradient_path_render(self.handle, C.byref(p), float(alpha), _dp(out),
+                                               _dp(bufs["img"]), _dp(bufs["cx0"]), _dp(bufs["cy0"]), _dp(bufs["cx1"]), _dp(bufs["cy1"]),
+                                               C.byref(rs), C.byref(ps)))
+        return (out, bufs, rs, ps) if return_buffers else out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().gdpt_scene_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def fourierSolve(width, height, imgData, imgGradX, imgGradY, dataCost=0.04, solver=defs.SOLVER_CG, tol=0.0,
+                 max_iters=0, return_stats=False):
+    """Screened-Poisson reconstruction on the GPU; arguments as the reference's fourierSolve
+    (src/render.cpp:172-175). Inputs HxWx3 (or flat W*H*3) float64; returns HxWx3."""
+    a = [np.ascontiguousarray(x, dtype=np.float64).reshape(height, width, 3) for x in (imgData, imgGradX, imgGradY)]
+    out = np.empty((height, width, 3), dtype=np.float64)
+    st = defs.GdptPoissonStats()
+    _check(lib().gdpt_poisson_solve_ex(int(width), int(height), _dp(a[0]), _dp(a[1]), _dp(a[2]), float(dataCost), _dp(out),
+                                       int(solver), float(tol), int(max_iters), C.byref(st)))
+    return (out, st) if return_stats else out
+
+
+def assemble_device(width, height, src_ptrs, dst_ptrs, stream=None):
+    _check(lib().gdpt_assemble_device(int(width), int(height), *[C.c_void_p(int(x)) for x in src_ptrs],
+                                      *[C.c_void_p(int(x)) for x in dst_ptrs], C.c_void_p(int(stream) if stream else 0)))
+
+
+def poisson_solve_device(width, height, c_ptr, gx_ptr, gy_ptr, out_ptr, alpha=0.04, solver=defs.SOLVER_CG, tol=0.0,
+                         max_iters=0, stream=None, want_stats=False):
+    st = defs.GdptPoissonStats() if want_stats else None
+    _check(lib().gdpt_poisson_solve_device(int(width), int(height), C.c_void_p(int(c_ptr)), C.c_void_p(int(gx_ptr)),
+                                           C.c_void_p(int(gy_ptr)), float(alpha), C.c_void_p(int(out_ptr)), int(solver),
+                                           float(tol), int(max_iters), C.c_void_p(int(stream) if stream else 0),
+                                           C.byref(st) if st is not None else None))
+    return st
+
+
+def imwrite(filename, image):
+    """.pfm (fp32) / .exr (fp16) by suffix, like src/image.cpp:135-173."""
+    img = np.ascontiguousarray(image, dtype=np.float64)
+    h, w, _ = img.shape
+    _check(lib().gdpt_imwrite(os.fsencode(filename), w, h, _dp(img)))
+
+
+def build_arch():
+    return lib().gdpt_build_arch().decode()

@@ -1,0 +1,78 @@
+// device_scene.h — HBM layout of the flattened scene (POD, shared by host upload code and HIP kernels).
+//
+// Traversal data is fp32 (what Embree receives from the reference, src/intersection.cpp:15-24,
+// src/shapes/triangle_mesh.inl:11-14); everything a shading computation touches is fp64
+// (Real = double, src/lajolla.h:23).
+#pragma once
+#include <stdint.h>
+
+#define GDPT_BVH_MAX_DEPTH 32      // builder guarantee; traversal stack has this many slots per lane
+#define GDPT_LEAF_MAX_PRIMS 4
+#define GDPT_SPHERE_FLAG 0x80000000u
+#define GDPT_CHILD_EMPTY INT32_MIN // child slot with no primitives (only in degenerate roots)
+
+// BVH2 node, 64 B, 64-B aligned: both children's boxes live in the parent so one fetch decides both.
+// child >= 0: index of an inner node. child < 0 (and != EMPTY): leaf, ~child = (first_prim << 2) | (count-1).
+struct DevBvhNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    int32_t left, right;
+    int32_t pad[2];
+};
+
+// Traversal record of one primitive, 48 B, in BVH leaf order.
+// Triangle: v0, e1 = fl(v1-v0), e2 = fl(v2-v0) in fp32; gid = global triangle id (index into DevTriShade).
+// Sphere:   gid = GDPT_SPHERE_FLAG | sphere index; the fp32 fields are unused (fp64 data in DevSphere).
+struct DevPrim {
+    float v0[3], e1[3], e2[3];
+    uint32_t gid;
+    uint32_t pad[2];
+};
+
+// fp64 per-triangle shading inputs (compute_shading_info, src/shapes/triangle_mesh.inl:77-169), 216 B.
+struct DevTriShade {
+    double p[3][3];
+    double n[3][3];      // vertex normals (has_normals)
+    double uv[3][2];     // vertex uvs (has_uvs), else the reference's default (0,0),(1,0),(1,1)
+    int32_t shape_id, prim_id, material_id, light_id; // light_id < 0: not an emitter
+    int32_t has_normals, has_uvs;
+};
+
+struct DevSphere {
+    double center[3];
+    double radius;
+    int32_t shape_id, material_id, light_id, pad;
+};
+
+struct DevImage {        // mip chain of one Mipmap1/Mipmap3 (src/mipmap.h:27-48), texels fp64 in one pool
+    int32_t channels, num_levels;
+    int32_t width[8], height[8];
+    int64_t offset[8];   // in doubles, into the texel pool
+};
+
+struct DevCamera {
+    double sample_to_cam[16];
+    double cam_to_world[16];
+    double org[3];       // xform_point(cam_to_world, 0) — constant per render (src/camera.cpp:42)
+    int32_t width, height;
+    int32_t filter_type, pad;
+    double filter_param;
+};
+
+// Everything a kernel needs, passed by value as one kernel argument (pointers are device pointers).
+struct DevSceneView {
+    DevCamera cam;
+    const DevBvhNode *nodes;
+    const DevPrim *prims;
+    const DevTriShade *tris;
+    const DevSphere *spheres;
+    const struct GdptMaterial *materials;   // same layout as the C ABI struct
+    const double *light_intensity;          // 3 per area light
+    const DevImage *images;
+    const double *texels;
+    int32_t num_nodes, num_prims, num_tris, num_spheres;
+    int32_t num_materials, num_lights, num_images;
+    int32_t max_depth, rr_depth;
+    int32_t all_lambert_const;              // every material is Lambertian with a constant reflectance
+    double isect_eps;                       // get_intersection_epsilon, src/scene.h:100-102
+};

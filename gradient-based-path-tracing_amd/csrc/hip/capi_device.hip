@@ -1,0 +1,410 @@
+// capi_device.hip — device-side entry points of include/gdpt.h: scene upload (own BVH2 build + HBM
+// layout), the five-buffer render, gradient assembly, the Poisson solve and the whole GradPath pipeline.
+#include "../../../include/gdpt.h"
+#include "../capi_common.h"
+#include "../device_scene.h"
+#include "../host/bvh.h"
+#include "poisson_kernels.h"
+#include "render_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+void ck(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+template <class T>
+T *upload(const std::vector<T> &v) {
+    if (v.empty()) return nullptr;
+    T *d = nullptr;
+    ck(hipMalloc((void **)&d, v.size() * sizeof(T)), "hipMalloc(scene)");
+    ck(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy(scene)");
+    return d;
+}
+
+} // namespace
+
+struct GdptScene {
+    int device = 0;
+    DevSceneView view{};
+    int bvh_depth = 0;
+    int scene_spp = 0;             // <sampler sampleCount> of the description (default spp)
+    std::vector<void *> allocations;
+    // cached output/work buffers for the host-pointer entry points
+    double *d_buf[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t buf_elems = 0;
+    gdpt::RenderCounters *d_counters = nullptr;
+    gdpt::RenderCounters *h_counters = nullptr; // pinned
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    template <class T>
+    T *keep(T *p) { if (p) allocations.push_back((void *)p); return p; }
+
+    void ensure_buffers(size_t elems) {
+        if (elems <= buf_elems) return;
+        for (auto &b : d_buf) { if (b) hipFree(b); b = nullptr; }
+        for (auto &b : d_buf) ck(hipMalloc((void **)&b, elems * sizeof(double)), "hipMalloc(image buffers)");
+        buf_elems = elems;
+    }
+    ~GdptScene() {
+        hipSetDevice(device);
+        for (void *p : allocations) hipFree(p);
+        for (auto &b : d_buf) if (b) hipFree(b);
+        if (d_counters) hipFree(d_counters);
+        if (h_counters) hipHostFree(h_counters);
+        if (ev0) hipEventDestroy(ev0);
+        if (ev1) hipEventDestroy(ev1);
+    }
+};
+
+namespace {
+
+void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
+    if (!desc) throw std::runtime_error("gdpt_scene_upload: null scene description");
+    int ndev = 0;
+    ck(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+    if (ndev <= 0) throw std::runtime_error("gdpt_scene_upload: no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) throw std::runtime_error("gdpt_scene_upload: bad device index");
+    ck(hipSetDevice(device), "hipSetDevice");
+    sc->device = device;
+
+    const GdptCamera &cam = desc->camera;
+    if (cam.width <= 0 || cam.height <= 0) throw std::runtime_error("gdpt_scene_upload: empty film");
+    for (int m = 0; m < desc->num_materials; m++) {
+        int t = desc->materials[m].type;
+        if (t == GDPT_MAT_ROUGHPLASTIC || t == GDPT_MAT_ROUGHDIELECTRIC)
+            throw std::runtime_error("gdpt_scene_upload: RoughPlastic/RoughDielectric are outside the GradPath hot-path subset (SURVEY.md §8(f) rank 4)");
+        if (t < 0 || t > GDPT_MAT_DISNEY_BSDF) throw std::runtime_error("gdpt_scene_upload: unknown material type");
+        for (int k = 0; k < GDPT_MAT_MAX_TEX; k++) {
+            const GdptTexture &tx = desc->materials[m].tex[k];
+            if (tx.type == GDPT_TEX_IMAGE && (tx.image_id < 0 || tx.image_id >= desc->num_images))
+                throw std::runtime_error("gdpt_scene_upload: texture references a missing image");
+        }
+    }
+
+    // ---- flatten primitives: triangles in (shape, triangle) order = global id; spheres after them ----
+    std::vector<DevTriShade> tris;
+    std::vector<DevSphere> spheres;
+    std::vector<DevPrim> prim_in;          // input order (gid order, spheres last)
+    std::vector<gdpt::PrimBounds> bounds;
+    float lb[3], ub[3];
+    for (int k = 0; k < 3; k++) { lb[k] = std::numeric_limits<float>::infinity(); ub[k] = -lb[k]; }
+    for (int s = 0; s < desc->num_shapes; s++) {
+        const GdptShape &sh = desc->shapes[s];
+        if (sh.material_id < 0 || sh.material_id >= desc->num_materials) throw std::runtime_error("gdpt_scene_upload: shape without a valid material");
+        if (sh.area_light_id >= desc->num_lights) throw std::runtime_error("gdpt_scene_upload: bad area light id");
+        if (sh.type != GDPT_SHAPE_TRIMESH) continue;
+        if (!sh.positions || !sh.indices) throw std::runtime_error("gdpt_scene_upload: mesh without positions/indices");
+        for (int i = 0; i < sh.num_vertices; i++)
+            for (int k = 0; k < 3; k++) { float p = (float)sh.positions[3 * i + k]; lb[k] = std::min(lb[k], p); ub[k] = std::max(ub[k], p); }
+        for (int t = 0; t < sh.num_triangles; t++) {
+            DevTriShade ts{};
+            DevPrim pr{};
+            gdpt::PrimBounds pb;
+            float v[3][3];
+            for (int k = 0; k < 3; k++) { pb.bmin[k] = std::numeric_limits<float>::infinity(); pb.bmax[k] = -pb.bmin[k]; }
+            for (int i = 0; i < 3; i++) {
+                int vi = sh.indices[3 * t + i];
+                if (vi < 0 || vi >= sh.num_vertices) throw std::runtime_error("gdpt_scene_upload: mesh index out of range");
+                for (int k = 0; k < 3; k++) {
+                    ts.p[i][k] = sh.positions[3 * vi + k];
+                    v[i][k] = (float)sh.positions[3 * vi + k];
+                    pb.bmin[k] = std::min(pb.bmin[k], v[i][k]); pb.bmax[k] = std::max(pb.bmax[k], v[i][k]);
+                    if (sh.normals) ts.n[i][k] = sh.normals[3 * vi + k];
+                }
+                if (sh.uvs) { ts.uv[i][0] = sh.uvs[2 * vi]; ts.uv[i][1] = sh.uvs[2 * vi + 1]; }
+            }
+            if (!sh.uvs) { // src/shapes/triangle_mesh.inl:86-90
+                ts.uv[0][0] = 0; ts.uv[0][1] = 0; ts.uv[1][0] = 1; ts.uv[1][1] = 0; ts.uv[2][0] = 1; ts.uv[2][1] = 1;
+            }
+            ts.shape_id = s; ts.prim_id = t; ts.material_id = sh.material_id; ts.light_id = sh.area_light_id;
+            ts.has_normals = sh.normals != nullptr; ts.has_uvs = sh.uvs != nullptr;
+            for (int k = 0; k < 3; k++) { pr.v0[k] = v[0][k]; pr.e1[k] = v[1][k] - v[0][k]; pr.e2[k] = v[2][k] - v[0][k]; }
+            pr.gid = (uint32_t)tris.size();
+            tris.push_back(ts); prim_in.push_back(pr); bounds.push_back(pb);
+        }
+    }
+    if (tris.size() >= (size_t)GDPT_SPHERE_FLAG / 8) throw std::runtime_error("gdpt_scene_upload: too many triangles");
+    for (int s = 0; s < desc->num_shapes; s++) {
+        const GdptShape &sh = desc->shapes[s];
+        if (sh.type != GDPT_SHAPE_SPHERE) continue;
+        DevSphere sp{};
+        DevPrim pr{};
+        gdpt::PrimBounds pb;
+        for (int k = 0; k < 3; k++) {
+            sp.center[k] = sh.center[k];
+            // scene bounds as Embree sees them: sphere_bounds_func stores double -> float (src/shapes/sphere.inl:1-10)
+            lb[k] = std::min(lb[k], (float)(sh.center[k] - sh.radius)); ub[k] = std::max(ub[k], (float)(sh.center[k] + sh.radius));
+            // BVH bounds: rounded outward so the box always contains the fp64 sphere
+            pb.bmin[k] = std::nextafterf((float)(sh.center[k] - sh.radius), -std::numeric_limits<float>::infinity());
+            pb.bmax[k] = std::nextafterf((float)(sh.center[k] + sh.radius), std::numeric_limits<float>::infinity());
+        }
+        sp.radius = sh.radius; sp.shape_id = s; sp.material_id = sh.material_id; sp.light_id = sh.area_light_id;
+        pr.gid = GDPT_SPHERE_FLAG | (uint32_t)spheres.size();
+        spheres.push_back(sp); prim_in.push_back(pr); bounds.push_back(pb);
+    }
+
+    gdpt::BvhBuildResult bvh = gdpt::build_bvh(bounds);
+    std::vector<DevPrim> prims(prim_in.size());
+    for (size_t i = 0; i < bvh.order.size(); i++) prims[i] = prim_in[bvh.order[i]];
+    sc->bvh_depth = bvh.depth;
+    if (bvh.depth > GDPT_BVH_MAX_DEPTH) throw std::runtime_error("gdpt_scene_upload: BVH deeper than the traversal stack (builder bug)");
+
+    // ---- textures: fp64 mip chains exactly as make_mipmap builds them (src/mipmap.h:27-48) ----
+    std::vector<DevImage> images;
+    std::vector<double> texels;
+    for (int i = 0; i < desc->num_images; i++) {
+        const GdptImage &im = desc->images[i];
+        if (im.width <= 0 || im.height <= 0 || (im.channels != 1 && im.channels != 3) || !im.texels)
+            throw std::runtime_error("gdpt_scene_upload: bad image");
+        DevImage di{};
+        di.channels = im.channels;
+        int size = std::max(im.width, im.height);
+        int num_levels = std::min((int)std::ceil(std::log2((double)size) + 1), 8);
+        di.num_levels = num_levels;
+        int pw = im.width, ph = im.height;
+        size_t prev_off = texels.size();
+        di.width[0] = pw; di.height[0] = ph; di.offset[0] = (int64_t)prev_off;
+        texels.insert(texels.end(), im.texels, im.texels + (size_t)pw * ph * im.channels);
+        for (int l = 1; l < num_levels; l++) {
+            int nw = std::max(pw / 2, 1), nh = std::max(ph / 2, 1);
+            size_t off = texels.size();
+            texels.resize(off + (size_t)nw * nh * im.channels);
+            auto P = [&](int x, int y, int c) { x = std::min(x, pw - 1); y = std::min(y, ph - 1); return texels[prev_off + ((size_t)y * pw + x) * im.channels + c]; };
+            for (int y = 0; y < nh; y++) for (int x = 0; x < nw; x++) for (int c = 0; c < im.channels; c++)
+                texels[off + ((size_t)y * nw + x) * im.channels + c] =
+                    (P(2 * x, 2 * y, c) + P(2 * x + 1, 2 * y, c) + P(2 * x, 2 * y + 1, c) + P(2 * x + 1, 2 * y + 1, c)) / 4.0;
+            di.width[l] = nw; di.height[l] = nh; di.offset[l] = (int64_t)off;
+            prev_off = off; pw = nw; ph = nh;
+        }
+        images.push_back(di);
+    }
+
+    std::vector<GdptMaterial> materials(desc->materials, desc->materials + desc->num_materials);
+    std::vector<double> light_intensity;
+    for (int l = 0; l < desc->num_lights; l++) for (int k = 0; k < 3; k++) light_intensity.push_back(desc->lights[l].intensity[k]);
+
+    DevSceneView &v = sc->view;
+    std::memcpy(v.cam.sample_to_cam, cam.sample_to_cam, sizeof(v.cam.sample_to_cam));
+    std::memcpy(v.cam.cam_to_world, cam.cam_to_world, sizeof(v.cam.cam_to_world));
+    {   // xform_point(cam_to_world, (0,0,0)), src/camera.cpp:42
+        const double *m = cam.cam_to_world;
+        double inv_w = 1.0 / m[15];
+        v.cam.org[0] = m[3] * inv_w; v.cam.org[1] = m[7] * inv_w; v.cam.org[2] = m[11] * inv_w;
+    }
+    v.cam.width = cam.width; v.cam.height = cam.height; v.cam.filter_type = cam.filter_type; v.cam.filter_param = cam.filter_param;
+    v.nodes = sc->keep(upload(bvh.nodes));
+    v.prims = sc->keep(upload(prims));
+    v.tris = sc->keep(upload(tris));
+    v.spheres = sc->keep(upload(spheres));
+    v.materials = sc->keep(upload(materials));
+    v.light_intensity = sc->keep(upload(light_intensity));
+    v.images = sc->keep(upload(images));
+    v.texels = sc->keep(upload(texels));
+    v.num_nodes = (int)bvh.nodes.size(); v.num_prims = (int)prims.size();
+    v.num_tris = (int)tris.size(); v.num_spheres = (int)spheres.size();
+    v.num_materials = desc->num_materials; v.num_lights = desc->num_lights; v.num_images = desc->num_images;
+    v.max_depth = desc->max_depth; v.rr_depth = desc->rr_depth;
+    v.all_lambert_const = 1;
+    for (auto &m : materials) if (m.type != GDPT_MAT_LAMBERTIAN || m.tex[0].type != GDPT_TEX_CONSTANT) v.all_lambert_const = 0;
+    // get_intersection_epsilon (src/scene.h:100-102) from Embree-style fp32 scene bounds (src/scene.cpp:29-33)
+    double dx = (double)ub[0] - (double)lb[0], dy = (double)ub[1] - (double)lb[1], dz = (double)ub[2] - (double)lb[2];
+    double radius = prims.empty() ? 0.0 : std::sqrt(dx * dx + dy * dy + dz * dz) / 2;
+    v.isect_eps = std::min(radius * 1e-5, 0.01);
+
+    ck(hipMalloc((void **)&sc->d_counters, sizeof(gdpt::RenderCounters)), "hipMalloc(counters)");
+    ck(hipHostMalloc((void **)&sc->h_counters, sizeof(gdpt::RenderCounters)), "hipHostMalloc(counters)");
+    ck(hipEventCreate(&sc->ev0), "hipEventCreate");
+    ck(hipEventCreate(&sc->ev1), "hipEventCreate");
+}
+
+struct Band { int spp, rng, row_begin, row_end, max_depth; };
+
+Band resolve(const GdptScene *sc, const GdptRenderParams *p) {
+    if (!sc) throw std::runtime_error("null scene handle");
+    Band b;
+    b.spp = (p && p->spp > 0) ? p->spp : 0;
+    b.rng = p ? p->rng_scheme : GDPT_RNG_SAMPLE;
+    b.row_begin = p ? p->row_begin : 0;
+    b.row_end = p ? p->row_end : 0;
+    if (b.row_begin == 0 && b.row_end == 0) b.row_end = sc->view.cam.height;
+    if (b.row_begin < 0 || b.row_end > sc->view.cam.height || b.row_begin >= b.row_end) throw std::runtime_error("gdpt_render: bad row band");
+    if (b.rng != GDPT_RNG_TILE && b.rng != GDPT_RNG_SAMPLE) throw std::runtime_error("gdpt_render: unknown rng_scheme");
+    if (b.rng == GDPT_RNG_TILE && ((b.row_begin % 16) != 0 || ((b.row_end % 16) != 0 && b.row_end != sc->view.cam.height)))
+        throw std::runtime_error("gdpt_render: GDPT_RNG_TILE bands must cover whole 16-pixel tile rows");
+    b.max_depth = (p && p->max_depth_override != 0) ? p->max_depth_override : sc->view.max_depth;
+    return b;
+}
+
+// Enqueues one render; returns after enqueue unless stats are requested.
+void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene_spp,
+                        double *img, double *cx0, double *cy0, double *cx1, double *cy1,
+                        hipStream_t stream, GdptRenderStats *stats) {
+    ck(hipSetDevice(sc->device), "hipSetDevice");
+    Band b = resolve(sc, params);
+    if (b.spp <= 0) b.spp = scene_spp;
+    if (b.spp <= 0) throw std::runtime_error("gdpt_render: samples per pixel must be > 0");
+    if (!img || !cx0 || !cy0 || !cx1 || !cy1) throw std::runtime_error("gdpt_render: null output buffer");
+    gdpt::RenderLaunch rl{};
+    rl.spp = b.spp; rl.rng_scheme = b.rng; rl.row_begin = b.row_begin; rl.row_end = b.row_end; rl.max_depth = b.max_depth;
+    rl.img = img; rl.cx0 = cx0; rl.cy0 = cy0; rl.cx1 = cx1; rl.cy1 = cy1;
+    rl.counters = sc->d_counters;
+    rl.count_traversal = stats && stats->nodes_visited == ~0ull;   // request flag: caller presets nodes_visited = UINT64_MAX
+    ck(hipMemsetAsync(sc->d_counters, 0, sizeof(gdpt::RenderCounters), stream), "hipMemsetAsync(counters)");
+    if (stats) ck(hipEventRecord(sc->ev0, stream), "hipEventRecord");
+    gdpt::launch_render(sc->view, rl, stream);
+    if (stats) {
+        ck(hipEventRecord(sc->ev1, stream), "hipEventRecord");
+        ck(hipMemcpyAsync(sc->h_counters, sc->d_counters, sizeof(gdpt::RenderCounters), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(counters)");
+        ck(hipStreamSynchronize(stream), "hipStreamSynchronize(render)");
+        float ms = 0;
+        ck(hipEventElapsedTime(&ms, sc->ev0, sc->ev1), "hipEventElapsedTime");
+        stats->samples = (uint64_t)sc->view.cam.width * (uint64_t)(b.row_end - b.row_begin) * (uint64_t)b.spp;
+        stats->rays = sc->h_counters->rays; stats->bounces = sc->h_counters->bounces;
+        stats->nonfinite_samples = sc->h_counters->nonfinite;
+        stats->nodes_visited = sc->h_counters->nodes; stats->tris_tested = sc->h_counters->prims;
+        stats->render_ms = ms;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+const char *gdpt_build_arch(void) { return "gfx950"; }
+
+int gdpt_scene_upload(const GdptSceneDesc *desc, int device, GdptScene **out_scene) {
+    return gdpt::guarded([&]() {
+        if (!out_scene) throw std::runtime_error("gdpt_scene_upload: null output");
+        std::unique_ptr<GdptScene> sc(new GdptScene());
+        build_scene(desc, device, sc.get());
+        sc->scene_spp = desc->samples_per_pixel;
+        *out_scene = sc.release();
+    });
+}
+
+void gdpt_scene_free(GdptScene *scene) {
+    if (!scene) return;
+    delete scene;
+}
+
+int gdpt_scene_info(const GdptScene *scene, int32_t *num_nodes, int32_t *num_tris, int32_t *num_spheres, int32_t *bvh_depth) {
+    return gdpt::guarded([&]() {
+        if (!scene) throw std::runtime_error("null scene handle");
+        if (num_nodes) *num_nodes = scene->view.num_nodes;
+        if (num_tris) *num_tris = scene->view.num_tris;
+        if (num_spheres) *num_spheres = scene->view.num_spheres;
+        if (bvh_depth) *bvh_depth = scene->bvh_depth;
+    });
+}
+
+int gdpt_render_device(GdptScene *scene, const GdptRenderParams *params,
+                       double *d_img, double *d_cx0, double *d_cy0, double *d_cx1, double *d_cy1,
+                       void *stream, GdptRenderStats *stats) {
+    return gdpt::guarded([&]() {
+        if (!scene) throw std::runtime_error("null scene handle");
+        render_device_impl(scene, params, scene->scene_spp, d_img, d_cx0, d_cy0, d_cx1, d_cy1, (hipStream_t)stream, stats);
+    });
+}
+
+int gdpt_render(GdptScene *scene, const GdptRenderParams *params,
+                double *img, double *cx0, double *cy0, double *cx1, double *cy1, GdptRenderStats *stats) {
+    return gdpt::guarded([&]() {
+        if (!scene) throw std::runtime_error("null scene handle");
+        if (!img || !cx0 || !cy0 || !cx1 || !cy1) throw std::runtime_error("gdpt_render: null output buffer");
+        ck(hipSetDevice(scene->device), "hipSetDevice");
+        size_t elems = (size_t)scene->view.cam.width * scene->view.cam.height * 3;
+        scene->ensure_buffers(elems);
+        Band b = resolve(scene, params);
+        double *host[5] = {img, cx0, cy0, cx1, cy1};
+        // rows outside the band keep the caller's contents: upload them first when rendering a partial band
+        bool partial = (b.row_begin != 0 || b.row_end != scene->view.cam.height);
+        if (partial) for (int k = 0; k < 5; k++) ck(hipMemcpy(scene->d_buf[k], host[k], elems * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(H2D)");
+        GdptRenderStats local{};
+        render_device_impl(scene, params, scene->scene_spp, scene->d_buf[0], scene->d_buf[1], scene->d_buf[2], scene->d_buf[3], scene->d_buf[4],
+                           nullptr, stats ? stats : &local);
+        for (int k = 0; k < 5; k++) ck(hipMemcpy(host[k], scene->d_buf[k], elems * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
+    });
+}
+
+int gdpt_assemble_device(int width, int height, const double *d_img, const double *d_cx0, const double *d_cy0,
+                         const double *d_cx1, const double *d_cy1, double *d_c, double *d_cx, double *d_cy, void *stream) {
+    return gdpt::guarded([&]() {
+        if (!d_img || !d_cx0 || !d_cy0 || !d_cx1 || !d_cy1 || !d_c || !d_cx || !d_cy) throw std::runtime_error("gdpt_assemble_device: null buffer");
+        gdpt::launch_assemble(width, height, d_img, d_cx0, d_cy0, d_cx1, d_cy1, d_c, d_cx, d_cy, (hipStream_t)stream);
+    });
+}
+
+int gdpt_poisson_solve_device(int width, int height, const double *d_c, const double *d_gx, const double *d_gy,
+                              double dataCost, double *d_out, int solver, double tol, int max_iters,
+                              void *stream, GdptPoissonStats *stats) {
+    return gdpt::guarded([&]() {
+        if (!d_c || !d_gx || !d_gy || !d_out) throw std::runtime_error("gdpt_poisson_solve_device: null buffer");
+        gdpt::PoissonResult r = gdpt::poisson_solve_device(width, height, d_c, d_gx, d_gy, dataCost, d_out, solver, tol, max_iters, (hipStream_t)stream);
+        if (stats) { stats->iterations = r.iterations; stats->solver = r.solver; stats->rel_residual = r.rel_residual; stats->solve_ms = r.solve_ms; }
+    });
+}
+
+int gdpt_poisson_solve_ex(int width, int height, const double *imgData, const double *imgGradX, const double *imgGradY,
+                          double dataCost, double *imgOut, int solver, double tol, int max_iters, GdptPoissonStats *stats) {
+    return gdpt::guarded([&]() {
+        if (!imgData || !imgGradX || !imgGradY || !imgOut) throw std::runtime_error("gdpt_poisson_solve: null buffer");
+        if (width <= 0 || height <= 0) throw std::runtime_error("gdpt_poisson_solve: empty image");
+        int ndev = 0;
+        ck(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+        if (ndev <= 0) throw std::runtime_error("gdpt_poisson_solve: no HIP device visible (this library has no CPU fallback)");
+        size_t bytes = (size_t)width * height * 3 * sizeof(double);
+        double *d[4] = {nullptr, nullptr, nullptr, nullptr};
+        auto cleanup = [&]() { for (auto p : d) if (p) hipFree(p); };
+        try {
+            for (auto &p : d) ck(hipMalloc((void **)&p, bytes), "hipMalloc(poisson io)");
+            ck(hipMemcpy(d[0], imgData, bytes, hipMemcpyHostToDevice), "hipMemcpy");
+            ck(hipMemcpy(d[1], imgGradX, bytes, hipMemcpyHostToDevice), "hipMemcpy");
+            ck(hipMemcpy(d[2], imgGradY, bytes, hipMemcpyHostToDevice), "hipMemcpy");
+            gdpt::PoissonResult r = gdpt::poisson_solve_device(width, height, d[0], d[1], d[2], dataCost, d[3], solver, tol, max_iters, nullptr);
+            ck(hipMemcpy(imgOut, d[3], bytes, hipMemcpyDeviceToHost), "hipMemcpy");
+            if (stats) { stats->iterations = r.iterations; stats->solver = r.solver; stats->rel_residual = r.rel_residual; stats->solve_ms = r.solve_ms; }
+        } catch (...) { cleanup(); throw; }
+        cleanup();
+    });
+}
+
+int gdpt_poisson_solve(int width, int height, const double *imgData, const double *imgGradX, const double *imgGradY,
+                       double dataCost, double *imgOut) {
+    return gdpt_poisson_solve_ex(width, height, imgData, imgGradX, imgGradY, dataCost, imgOut, GDPT_SOLVER_CG, 0.0, 0, nullptr);
+}
+
+int gdpt_gradient_path_render(GdptScene *scene, const GdptRenderParams *params, double dataCost, double *out_image,
+                              double *img, double *cx0, double *cy0, double *cx1, double *cy1,
+                              GdptRenderStats *rstats, GdptPoissonStats *pstats) {
+    return gdpt::guarded([&]() {
+        if (!scene || !out_image) throw std::runtime_error("gdpt_gradient_path_render: null argument");
+        ck(hipSetDevice(scene->device), "hipSetDevice");
+        const int w = scene->view.cam.width, h = scene->view.cam.height;
+        size_t elems = (size_t)w * h * 3;
+        scene->ensure_buffers(elems);
+        double **b = scene->d_buf;
+        GdptRenderParams p = params ? *params : GdptRenderParams{};
+        p.row_begin = 0; p.row_end = 0;   // the solve is global: whole image only
+        GdptRenderStats local{};
+        render_device_impl(scene, &p, scene->scene_spp, b[0], b[1], b[2], b[3], b[4], nullptr, rstats ? rstats : &local);
+        gdpt::launch_assemble(w, h, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], nullptr);
+        gdpt::PoissonResult r = gdpt::poisson_solve_device(w, h, b[5], b[6], b[7], dataCost, b[8], GDPT_SOLVER_CG, 0.0, 0, nullptr);
+        if (pstats) { pstats->iterations = r.iterations; pstats->solver = r.solver; pstats->rel_residual = r.rel_residual; pstats->solve_ms = r.solve_ms; }
+        ck(hipMemcpy(out_image, b[8], elems * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
+        double *host[5] = {img, cx0, cy0, cx1, cy1};
+        for (int k = 0; k < 5; k++) if (host[k]) ck(hipMemcpy(host[k], b[k], elems * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
+    });
+}
+
+} // extern "C"

@@ -1,0 +1,282 @@
+// device_trace.h — closest-hit BVH2 traversal with an LDS stack, shading-info reconstruction and the
+// camera for the HIP kernels. Replaces Embree behind intersect() (src/intersection.cpp:7-65).
+//
+// Closest hit is DEFINED as: minimum fp32 t over all primitives whose test accepts the ray
+// (tnear <= t < tfar), ties broken by the lowest global primitive id. That makes the result
+// independent of traversal order, so this BVH walk, the oracle's brute force and the oracle's own
+// BVH must all return the same hit; box tests only have to be conservative.
+#pragma once
+#include "device_bsdf.h"
+
+namespace gd {
+
+struct Hit { float t, u, v, ngx, ngy, ngz; int gid; };   // gid < 0: miss
+
+struct TraceCounters { unsigned long long nodes, prims; };
+
+// fp32 Moller-Trumbore, two-sided; every operation rounds once (no FMA contraction), sums left to right.
+// Bit-for-bit the oracle's tri_hit (oracle/oracle.cpp).
+GD bool tri_hit(const float o[3], const float d[3], float tnear, float tfar, const DevPrim &tr, float &t, float &u, float &v) {
+#pragma clang fp contract(off)
+    const float *e1 = tr.e1, *e2 = tr.e2;
+    float px = d[1] * e2[2] - d[2] * e2[1];
+    float py = d[2] * e2[0] - d[0] * e2[2];
+    float pz = d[0] * e2[1] - d[1] * e2[0];
+    float det = e1[0] * px + e1[1] * py + e1[2] * pz;
+    if (!(det != 0.0f)) return false;
+    float inv = 1.0f / det;
+    float sx = o[0] - tr.v0[0], sy = o[1] - tr.v0[1], sz = o[2] - tr.v0[2];
+    u = (sx * px + sy * py + sz * pz) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    float qx = sy * e1[2] - sz * e1[1];
+    float qy = sz * e1[0] - sx * e1[2];
+    float qz = sx * e1[1] - sy * e1[0];
+    v = (d[0] * qx + d[1] * qy + d[2] * qz) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+    t = (e2[0] * qx + e2[1] * qy + e2[2] * qz) * inv;
+    return (t >= tnear && t < tfar);
+}
+
+// Sphere primitive: fp64 quadratic on the fp32 ray (src/shapes/sphere.inl:15-106).
+GD bool sphere_hit(const float o[3], const float d[3], float tnear, float tfar, const DevSphere &sp, Hit &h) {
+#pragma clang fp contract(off)
+    double ox = o[0] - sp.center[0], oy = o[1] - sp.center[1], oz = o[2] - sp.center[2];
+    double dx = d[0], dy = d[1], dz = d[2];
+    double A = dx * dx + dy * dy + dz * dz;
+    double B = 2 * (dx * ox + dy * oy + dz * oz);
+    double C = (ox * ox + oy * oy + oz * oz) - sp.radius * sp.radius;
+    double t0, t1;
+    if (A == 0) {
+        if (B == 0) return false;
+        t0 = t1 = -C / B;
+    } else {
+        double disc = B * B - 4 * A * C;
+        if (disc < 0) return false;
+        double rd = sqrt(disc);
+        if (B >= 0) { t0 = (-B - rd) / (2 * A); t1 = 2 * C / (-B - rd); }
+        else { t0 = 2 * C / (-B + rd); t1 = (-B + rd) / (2 * A); }
+    }
+    if (t0 > t1) { double tmp = t0; t0 = t1; t1 = tmp; }
+    double rn = tnear, rf = tfar, t = -1;
+    if (t0 >= rn && t0 < rf) t = t0;
+    if (t1 >= rn && t1 < rf && t < 0) t = t1;
+    if (!(t >= rn && t < rf)) return false;
+    double gx = ((double)o[0] + t * dx) - sp.center[0], gy = ((double)o[1] + t * dy) - sp.center[1], gz = ((double)o[2] + t * dz) - sp.center[2];
+    double inv_r = 1.0 / sp.radius;
+    double cy = fmin(fmax(gy * inv_r, -1.0), 1.0);
+    double elevation = acos(cy);
+    double azimuth = atan2(gz * inv_r, gx * inv_r);
+    h.ngx = (float)gx; h.ngy = (float)gy; h.ngz = (float)gz;
+    h.u = (float)(azimuth / kTwoPi); h.v = (float)(elevation / kPi);
+    h.t = (float)t;
+    return true;
+}
+
+GD void test_prim(const DevSceneView &sv, const DevPrim &pr, const float o[3], const float d[3], float tnear, float tfar, Hit &best) {
+    unsigned gid = pr.gid;
+    if (!(gid & GDPT_SPHERE_FLAG)) {
+        float t, u, v;
+        if (!tri_hit(o, d, tnear, tfar, pr, t, u, v)) return;
+        if (best.gid >= 0 && !(t < best.t || (t == best.t && (int)gid < best.gid))) return;
+        best.t = t; best.u = u; best.v = v; best.gid = (int)gid;
+        {
+#pragma clang fp contract(off)
+            best.ngx = pr.e1[1] * pr.e2[2] - pr.e1[2] * pr.e2[1];
+            best.ngy = pr.e1[2] * pr.e2[0] - pr.e1[0] * pr.e2[2];
+            best.ngz = pr.e1[0] * pr.e2[1] - pr.e1[1] * pr.e2[0];
+        }
+    } else {
+        Hit h;
+        if (!sphere_hit(o, d, tnear, tfar, sv.spheres[gid & ~GDPT_SPHERE_FLAG], h)) return;
+        int sg = sv.num_tris + (int)(gid & ~GDPT_SPHERE_FLAG);   // spheres order after all triangles
+        if (best.gid >= 0 && !(h.t < best.t || (h.t == best.t && sg < best.gid))) return;
+        h.gid = sg;
+        best = h;
+    }
+}
+
+// Conservative slab test: returns entry distance in `tin`; never rejects a box that holds a primitive
+// able to report t <= tbest.
+GD bool box_hit(const float *mn, const float *mx, const float o[3], const float inv[3], float tnear, float tbest, float &tin) {
+    float t0 = tnear, t1 = tbest;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float a = (mn[k] - o[k]) * inv[k], b = (mx[k] - o[k]) * inv[k];
+        float lo = fminf(a, b), hi = fmaxf(a, b);       // NaN (0*inf on flat boxes) is dropped by fmin/fmax
+        lo = lo - fabsf(lo) * 4e-7f; hi = hi + fabsf(hi) * 4e-7f;
+        t0 = fmaxf(t0, lo); t1 = fminf(t1, hi);
+    }
+    tin = t0;
+    return t0 <= t1;
+}
+
+// `stack` points at this lane's slot 0 in LDS; consecutive levels are `stride` ints apart
+// (stride = block size, so a wave's accesses to one level hit 64 consecutive banks).
+template <bool COUNT>
+GD Hit closest_hit(const DevSceneView &sv, const float o[3], const float d[3], float tnear, float tfar,
+                   int *stack, int stride, TraceCounters &tc) {
+    Hit best; best.gid = -1; best.t = tfar; best.u = best.v = 0; best.ngx = best.ngy = best.ngz = 0;
+    if (sv.num_nodes == 0) return best;
+    float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+    int sp = 0;
+    int cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const DevBvhNode &n = sv.nodes[cur];
+            if (COUNT) tc.nodes++;
+            float tb = best.t;   // == tfar until something is hit (t < tfar, so <= is safe)
+            float tl, tr;
+            bool hl = (n.left != GDPT_CHILD_EMPTY) && box_hit(n.lmin, n.lmax, o, inv, tnear, tb, tl);
+            bool hr = (n.right != GDPT_CHILD_EMPTY) && box_hit(n.rmin, n.rmax, o, inv, tnear, tb, tr);
+            if (hl && hr) {
+                int nearc = n.left, farc = n.right;
+                if (tr < tl) { nearc = n.right; farc = n.left; }
+                stack[sp * stride] = farc; sp++;
+                cur = nearc;
+                continue;
+            } else if (hl) { cur = n.left; continue; }
+            else if (hr) { cur = n.right; continue; }
+        } else {
+            unsigned packed = ~(unsigned)cur;
+            unsigned first = packed >> 2, cnt = (packed & 3u) + 1u;
+            for (unsigned i = 0; i < cnt; i++) {
+                if (COUNT) tc.prims++;
+                test_prim(sv, sv.prims[first + i], o, d, tnear, tfar, best);
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = stack[sp * stride];
+    }
+    return best;
+}
+
+// ---- intersect() post-processing: src/intersection.cpp:37-63 + compute_shading_info ----------------
+struct Ray { D3 org, dir; double tnear, tfar; };
+
+GD void shading_info_tri(const DevTriShade &ts, D2 st, D3 gn, D2 &uv, Frame &frame, double &inv_uv_size) {
+    // src/shapes/triangle_mesh.inl:77-169 (mean curvature is never read on the GradPath path: skipped)
+    double b0 = 1 - st.x - st.y;
+    uv.x = b0 * ts.uv[0][0] + st.x * ts.uv[1][0] + st.y * ts.uv[2][0];
+    uv.y = b0 * ts.uv[0][1] + st.x * ts.uv[1][1] + st.y * ts.uv[2][1];
+    D3 p0 = mk(ts.p[0][0], ts.p[0][1], ts.p[0][2]), p1 = mk(ts.p[1][0], ts.p[1][1], ts.p[1][2]), p2 = mk(ts.p[2][0], ts.p[2][1], ts.p[2][2]);
+    double dsx = ts.uv[2][0] - ts.uv[0][0], dsy = ts.uv[2][1] - ts.uv[0][1];   // duvds
+    double dtx = ts.uv[2][0] - ts.uv[1][0], dty = ts.uv[2][1] - ts.uv[1][1];   // duvdt
+    double det = dsx * dty - dtx * dsy;
+    D3 dpdu, dpdv;
+    if (fabs(det) > (double)1e-8f) {
+        double dsdu = dty / det, dtdu = -dsy / det, dsdv = dtx / det, dtdv = -dsx / det;
+        D3 dpds = p2 - p0, dpdt = p2 - p1;
+        dpdu = dpds * dsdu + dpdt * dtdu;
+        dpdv = dpds * dsdv + dpdt * dtdv;
+    } else {
+        coordinate_system(gn, dpdu, dpdv);
+    }
+    D3 sn = gn;
+    if (ts.has_normals) {
+        D3 n0 = mk(ts.n[0][0], ts.n[0][1], ts.n[0][2]), n1 = mk(ts.n[1][0], ts.n[1][1], ts.n[1][2]), n2 = mk(ts.n[2][0], ts.n[2][1], ts.n[2][2]);
+        sn = normalize(b0 * n0 + st.x * n1 + st.y * n2);
+    }
+    D3 tangent = normalize(dpdu - sn * dot(sn, dpdu));
+    D3 bitangent = normalize(cross(sn, tangent));
+    frame.x = tangent; frame.y = bitangent; frame.n = sn;
+    inv_uv_size = fmax(length(dpdu), length(dpdv));
+}
+
+GD void shading_info_sphere(const DevSphere &sp, D2 st, D3 gn, D2 &uv, Frame &frame, double &inv_uv_size) {
+    // src/shapes/sphere.inl:243-268 (st used as radians although it is in [0,1] units — kept)
+    double r = sp.radius;
+    double su, cu, sv_, cv;
+    sincos(st.x, &su, &cu);
+    sincos(st.y, &sv_, &cv);
+    D3 dpdu = mk(-r * su * sv_, r * cu * sv_, 0.0);
+    D3 dpdv = mk(r * cu * cv, r * su * cv, -r * sv_);
+    D3 tangent = normalize(dpdu - gn * dot(gn, dpdu));
+    frame.x = tangent; frame.y = normalize(cross(gn, tangent)); frame.n = gn;
+    uv = st;
+    inv_uv_size = (length(dpdu) + length(dpdv)) / 2;
+}
+
+// Builds the PathVertex of a hit. rd_spread/rd_radius: RayDifferential of the query (src/ray.h:26-40).
+GD void make_vertex(const DevSceneView &sv, const Ray &ray, const Hit &h, double rd_radius, double rd_spread, Vertex &v) {
+    v.position = ray.org + ray.dir * (double)h.t;
+    D3 gn = normalize(mk((double)h.ngx, (double)h.ngy, (double)h.ngz));
+    D2 st; st.x = (double)h.u; st.y = (double)h.v;
+    double inv_uv_size;
+    if (h.gid < sv.num_tris) {
+        const DevTriShade &ts = sv.tris[h.gid];
+        v.material_id = ts.material_id; v.light_id = ts.light_id;
+        shading_info_tri(ts, st, gn, v.uv, v.frame, inv_uv_size);
+    } else {
+        const DevSphere &sp = sv.spheres[h.gid - sv.num_tris];
+        v.material_id = sp.material_id; v.light_id = sp.light_id;
+        shading_info_sphere(sp, st, gn, v.uv, v.frame, inv_uv_size);
+    }
+    D3 dlt = ray.org - v.position;
+    double dist = sqrt(dot(dlt, dlt));
+    double ray_radius = rd_radius + rd_spread * dist;
+    v.uv_screen_size = ray_radius / inv_uv_size;
+    if (dot(gn, v.frame.n) < 0) gn = -gn;
+    v.gn = gn;
+}
+
+template <bool COUNT>
+GD bool intersect(const DevSceneView &sv, const Ray &ray, double rd_radius, double rd_spread, Vertex &v,
+                  int *stack, int stride, TraceCounters &tc) {
+    float o[3] = {(float)ray.org.x, (float)ray.org.y, (float)ray.org.z};
+    float d[3] = {(float)ray.dir.x, (float)ray.dir.y, (float)ray.dir.z};
+    Hit h = closest_hit<COUNT>(sv, o, d, (float)ray.tnear, (float)ray.tfar, stack, stride, tc);
+    if (h.gid < 0) return false;
+    make_vertex(sv, ray, h, rd_radius, rd_spread, v);
+    return true;
+}
+
+// emission(), src/intersection.cpp:87-98 + src/lights/diffuse_area_light.inl:15-20
+GD D3 emission(const DevSceneView &sv, const Vertex &v, D3 view_dir) {
+    if (dot(v.gn, view_dir) <= 0) return splat(0);
+    const double *L = sv.light_intensity + 3 * v.light_id;
+    return mk(L[0], L[1], L[2]);
+}
+
+// ---- camera, src/camera.cpp:23-47 + src/filters/*.inl ----------------------------------------------
+GD D2 filter_sample(int type, double param, double rx, double ry) {
+    D2 o;
+    if (type == GDPT_FILTER_BOX) { o.x = (2 * rx - 1) * (param / 2); o.y = (2 * ry - 1) * (param / 2); }
+    else if (type == GDPT_FILTER_GAUSSIAN) {
+        double r = param * sqrt(-2 * log(fmax(rx, 1e-8)));
+        double s, c;
+        sincos(2 * kPi * ry, &s, &c);
+        o.x = r * c; o.y = r * s;
+    } else {
+        double h = param / 2;
+        o.x = rx < 0.5 ? h * (sqrt(2 * rx) - 1) : h * (1 - sqrt(1 - 2 * (rx - 0.5)));
+        o.y = ry < 0.5 ? h * (sqrt(2 * ry) - 1) : h * (1 - sqrt(1 - 2 * (ry - 0.5)));
+    }
+    return o;
+}
+GD D3 xform_point(const double *m, D3 p) {
+    double tx = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+    double ty = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    double tz = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+    double tw = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+    double inv_w = 1.0 / tw;
+    return mk(tx * inv_w, ty * inv_w, tz * inv_w);
+}
+GD D3 xform_vector(const double *m, D3 v) {
+    return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+GD Ray sample_primary(const DevCamera &cam, double sx, double sy) {
+    double ppx = sx * cam.width, ppy = sy * cam.height;
+    double fx = floor(ppx), fy = floor(ppy);
+    D2 off = filter_sample(cam.filter_type, cam.filter_param, ppx - fx, ppy - fy);
+    double rx = (fx + 0.5 + off.x) / cam.width, ry = (fy + 0.5 + off.y) / cam.height;
+    D3 pt = xform_point(cam.sample_to_cam, mk(rx, ry, 0.0));
+    D3 dir = normalize(pt);
+    Ray r;
+    r.org = mk(cam.org[0], cam.org[1], cam.org[2]);
+    r.dir = normalize(xform_vector(cam.cam_to_world, dir));
+    r.tnear = 0; r.tfar = __builtin_huge_val();
+    return r;
+}
+
+} // namespace gd

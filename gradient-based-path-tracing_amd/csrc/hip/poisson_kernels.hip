@@ -1,0 +1,317 @@
+// poisson_kernels.hip — gradient assembly and the screened-Poisson reconstruction for gfx950.
+//
+// Reference: fourierSolve (src/render.cpp:172-254) solves, per channel,
+//     argmin_f  alpha*|f-u|^2 + |grad f - g|^2
+// with a DCT-I (FFTW REDFT00), whose basis implies whole-sample-symmetric (mirror, edge not
+// repeated) boundaries, and then overrides the DC coefficient with sum(w*u) (:205-211,:239).
+// The same f is the solution of the linear system
+//     W (alpha I - L) f = W h,     h = alpha*u - D(g)                                 (:213-224)
+// where L is the 5-point Laplacian with mirror boundaries (x-part 2(f[1]-f[0]) at x=0), W = diag(w_x w_y)
+// with w = 1 on borders and 2 inside (it makes the operator symmetric), followed by the constant
+//     f += (sum(w u) - sum(w h)/alpha) / (4 (W-1)(H-1))                                per channel
+// which reproduces the DC override (derivation: SURVEY.md §8(a) P1, Appendix A.2).
+// Here: conjugate gradients on that system, all three channels as one block-diagonal system
+// (N = W*H*3 unknowns, interleaved RGB exactly as Image3::data), fp64, x0 = u.
+//
+// Per iteration two kernels and no host round trip:
+//   cg_step_a: p' = r + beta p (recomputed on the 5 taps, p double-buffered), q = A p', partial <p',q>
+//   cg_step_b: x += a p', r -= a q, partial <r,r>
+// Scalars are reduced from per-block partials by every block in the same fixed order (deterministic).
+#include "poisson_kernels.h"
+#include "../../../include/gdpt.h"
+
+#include <chrono>
+#include <cmath>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+namespace gp {
+
+constexpr int kBlock = 256;
+constexpr int kMaxBlocks = 1024;
+
+struct CgState {
+    double rr[2];         // <r,r> ping-pong by iteration parity
+    double bb;            // <b,b>
+    double wu[3], wh[3];  // sum(w*u), sum(w*h) per channel
+    double tol2;          // tol^2
+    int iters;
+    int converged;
+};
+
+__device__ __forceinline__ double block_sum(double v, double *red) {
+    // fixed-order: xor tree inside each wave, then the 4 wave totals in index order
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    double s = red[0];
+#pragma unroll
+    for (int k = 1; k < kBlock / 64; k++) s += red[k];
+    return s;
+}
+__device__ __forceinline__ double reduce_partials(const double *part, int n, double *red) {
+    double v = 0;
+    for (int i = threadIdx.x; i < n; i += kBlock) v += part[i];
+    return block_sum(v, red);
+}
+
+struct Geo { int w, h, n3, row; };   // row = 3*w doubles per image row
+
+__device__ __forceinline__ double weight(const Geo &g, int x, int y) {
+    double wx = (x > 0 && x < g.w - 1) ? 2.0 : 1.0, wy = (y > 0 && y < g.h - 1) ? 2.0 : 1.0;
+    return wx * wy;
+}
+// (L v)[i] with mirror boundaries; `at(j)` returns v[j]
+template <class F>
+__device__ __forceinline__ double laplace(const Geo &g, int i, int x, int y, double vi, F at) {
+    double lx, ly;
+    if (x > 0 && x < g.w - 1) lx = (at(i - 3) + at(i + 3)) - 2.0 * vi;
+    else if (x == 0) lx = 2.0 * (at(i + 3) - vi);
+    else lx = 2.0 * (at(i - 3) - vi);
+    if (y > 0 && y < g.h - 1) ly = (at(i - g.row) + at(i + g.row)) - 2.0 * vi;
+    else if (y == 0) ly = 2.0 * (at(i + g.row) - vi);
+    else ly = 2.0 * (at(i - g.row) - vi);
+    return lx + ly;
+}
+
+__global__ __launch_bounds__(kBlock) void assemble_kernel(Geo g, const double *img, const double *cx0, const double *cy0,
+                                                          const double *cx1, const double *cy1, double *c, double *cx, double *cy) {
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < g.n3; i += gridDim.x * kBlock) {
+        int y = i / g.row, x = (i - y * g.row) / 3;
+        c[i] = img[i];
+        cx[i] = (x == 0) ? cx0[i] : cx0[i] + cx1[i - 3];
+        cy[i] = (y == 0) ? cy0[i] : cy0[i] + cy1[i - g.row];
+    }
+}
+
+// h = alpha*u - D(g) (src/render.cpp:213-224); b = w*h; x0 = u; r0 = b - W(alpha I - L)x0; p = 0.
+// partials layout: [0] rr, [1] bb, [2..4] wu, [5..7] wh, each gridDim.x long.
+__global__ __launch_bounds__(kBlock) void cg_init_kernel(Geo g, double alpha, const double *u, const double *gx, const double *gy,
+                                                         double *x, double *r, double *p0, double *p1, double *partials) {
+    __shared__ double red[kBlock / 64];
+    double s_rr = 0, s_bb = 0, s_wu[3] = {0, 0, 0}, s_wh[3] = {0, 0, 0};
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < g.n3; i += gridDim.x * kBlock) {
+        int y = i / g.row, col = i - y * g.row, xx = col / 3, ch = col - xx * 3;
+        double ui = u[i];
+        double hv = alpha * ui;
+        if (xx > 0 && xx < g.w - 1) hv -= (gx[i + 3] - gx[i]); else hv -= (-2.0 * gx[i]);
+        if (y > 0 && y < g.h - 1) hv -= (gy[i + g.row] - gy[i]); else hv -= (-2.0 * gy[i]);
+        double wgt = weight(g, xx, y);
+        double b = wgt * hv;
+        double Au = wgt * (alpha * ui - laplace(g, i, xx, y, ui, [&](int j) { return u[j]; }));
+        double ri = b - Au;
+        x[i] = ui; r[i] = ri; p0[i] = 0.0; p1[i] = 0.0;
+        s_rr += ri * ri; s_bb += b * b;
+#pragma unroll
+        for (int k = 0; k < 3; k++) if (ch == k) { s_wu[k] += wgt * ui; s_wh[k] += wgt * hv; }
+    }
+    const int nb = gridDim.x;
+    double v;
+    v = block_sum(s_rr, red); if (threadIdx.x == 0) partials[0 * nb + blockIdx.x] = v;
+    v = block_sum(s_bb, red); if (threadIdx.x == 0) partials[1 * nb + blockIdx.x] = v;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        v = block_sum(s_wu[k], red); if (threadIdx.x == 0) partials[(2 + k) * nb + blockIdx.x] = v;
+        v = block_sum(s_wh[k], red); if (threadIdx.x == 0) partials[(5 + k) * nb + blockIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void cg_init_reduce_kernel(int nb, const double *partials, CgState *st, double tol) {
+    __shared__ double red[kBlock / 64];
+    double bb = reduce_partials(partials + 1 * nb, nb, red);
+    double wu[3], wh[3];
+    for (int k = 0; k < 3; k++) { wu[k] = reduce_partials(partials + (2 + k) * nb, nb, red); wh[k] = reduce_partials(partials + (5 + k) * nb, nb, red); }
+    if (threadIdx.x == 0) {
+        st->bb = bb; st->rr[0] = 1.0; st->rr[1] = 1.0;
+        for (int k = 0; k < 3; k++) { st->wu[k] = wu[k]; st->wh[k] = wh[k]; }
+        st->tol2 = tol * tol; st->iters = 0; st->converged = 0;
+    }
+}
+
+// iteration `it` (parity selects the p buffers): p_out = r + beta p_in; q = A p_out; partial <p_out,q>
+__global__ __launch_bounds__(kBlock) void cg_step_a(Geo g, double alpha, int it, const double *r, const double *p_in, double *p_out,
+                                                    double *q, const double *part_rr, double *part_pq, CgState *st) {
+    __shared__ double red[kBlock / 64];
+    const int nb = gridDim.x;
+    double rr_new = reduce_partials(part_rr, nb, red);
+    const double rr_old = st->rr[(it + 1) & 1];
+    const double bb = st->bb, tol2 = st->tol2;
+    if (rr_new <= tol2 * bb || st->converged) {        // uniform over the whole grid: same inputs in every block
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->converged = 1;
+        return;
+    }
+    const double beta = rr_new / rr_old;               // first iteration: p_in = 0, beta arbitrary
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->rr[it & 1] = rr_new;
+    double s = 0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < g.n3; i += gridDim.x * kBlock) {
+        int y = i / g.row, xx = (i - y * g.row) / 3;
+        double pi = r[i] + beta * p_in[i];
+        double lap = laplace(g, i, xx, y, pi, [&](int j) { return r[j] + beta * p_in[j]; });
+        double qi = weight(g, xx, y) * (alpha * pi - lap);
+        p_out[i] = pi; q[i] = qi;
+        s += pi * qi;
+    }
+    double v = block_sum(s, red);
+    if (threadIdx.x == 0) part_pq[blockIdx.x] = v;
+}
+
+__global__ __launch_bounds__(kBlock) void cg_step_b(Geo g, int it, const double *p, const double *q, double *x, double *r,
+                                                    const double *part_pq, double *part_rr, CgState *st) {
+    __shared__ double red[kBlock / 64];
+    if (st->converged) return;
+    const int nb = gridDim.x;
+    double pq = reduce_partials(part_pq, nb, red);
+    const double a = st->rr[it & 1] / pq;
+    double s = 0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < g.n3; i += gridDim.x * kBlock) {
+        x[i] += a * p[i];
+        double ri = r[i] - a * q[i];
+        r[i] = ri;
+        s += ri * ri;
+    }
+    double v = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        part_rr[blockIdx.x] = v;
+        if (blockIdx.x == 0) st->iters = it + 1;
+    }
+}
+
+// out = x + (sum(w u) - sum(w h)/alpha) / (4 (W-1)(H-1)) per channel  (the DC override, src/render.cpp:239)
+__global__ __launch_bounds__(kBlock) void cg_finalize_kernel(Geo g, double alpha, const double *x, double *out,
+                                                             const double *part_rr, int nb, CgState *st, double *rel_res) {
+    __shared__ double red[kBlock / 64];
+    double shift[3];
+    double denom = 4.0 * (double)(g.w - 1) * (double)(g.h - 1);
+    for (int k = 0; k < 3; k++) shift[k] = (st->wu[k] - st->wh[k] / alpha) / denom;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < g.n3; i += gridDim.x * kBlock) {
+        int ch = i % 3;
+        out[i] = x[i] + (ch == 0 ? shift[0] : (ch == 1 ? shift[1] : shift[2]));
+    }
+    if (blockIdx.x == 0) {
+        double rr = reduce_partials(part_rr, nb, red);
+        if (threadIdx.x == 0) *rel_res = (st->bb > 0) ? sqrt(rr / st->bb) : 0.0;
+    }
+}
+
+} // namespace gp
+
+namespace gdpt {
+
+namespace {
+
+void ck(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+struct Workspace {
+    size_t n3 = 0;
+    double *x = nullptr, *r = nullptr, *q = nullptr, *p0 = nullptr, *p1 = nullptr, *partials = nullptr, *rel = nullptr;
+    gp::CgState *state = nullptr;
+    gp::CgState *h_state = nullptr;   // pinned
+    double *h_rel = nullptr;          // pinned
+    int device = -1;
+    void release() {
+        for (double *p : {x, r, q, p0, p1, partials, rel}) if (p) hipFree(p);
+        if (state) hipFree(state);
+        if (h_state) hipHostFree(h_state);
+        if (h_rel) hipHostFree(h_rel);
+        *this = Workspace();
+    }
+    void ensure(size_t n) {
+        int dev = 0;
+        ck(hipGetDevice(&dev), "hipGetDevice");
+        if (n <= n3 && dev == device) return;
+        release();
+        device = dev; n3 = n;
+        for (double **p : {&x, &r, &q, &p0, &p1}) ck(hipMalloc((void **)p, n * sizeof(double)), "hipMalloc(poisson workspace)");
+        ck(hipMalloc((void **)&partials, 10 * gp::kMaxBlocks * sizeof(double)), "hipMalloc(partials)");
+        ck(hipMalloc((void **)&rel, sizeof(double)), "hipMalloc(rel)");
+        ck(hipMalloc((void **)&state, sizeof(gp::CgState)), "hipMalloc(state)");
+        ck(hipHostMalloc((void **)&h_state, sizeof(gp::CgState)), "hipHostMalloc");
+        ck(hipHostMalloc((void **)&h_rel, sizeof(double)), "hipHostMalloc");
+    }
+};
+Workspace g_ws;
+std::mutex g_ws_mu;
+
+} // namespace
+
+void poisson_release_workspace() {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    g_ws.release();
+}
+
+void launch_assemble(int w, int h, const double *img, const double *cx0, const double *cy0, const double *cx1, const double *cy1,
+                     double *c, double *cx, double *cy, hipStream_t stream) {
+    if (w <= 0 || h <= 0) throw std::runtime_error("assemble: empty image");
+    gp::Geo g{w, h, w * h * 3, w * 3};
+    int nb = std::min(gp::kMaxBlocks * 2, (g.n3 + gp::kBlock - 1) / gp::kBlock);
+    hipLaunchKernelGGL(gp::assemble_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, img, cx0, cy0, cx1, cy1, c, cx, cy);
+    ck(hipGetLastError(), "assemble kernel launch");
+}
+
+PoissonResult poisson_solve_device(int w, int h, const double *d_c, const double *d_gx, const double *d_gy, double alpha,
+                                   double *d_out, int solver, double tol, int max_iters, hipStream_t stream) {
+    if (w < 2 || h < 2) throw std::runtime_error("poisson: width and height must be >= 2 (the reference divides by (W-1)(H-1))");
+    if (!(alpha > 0)) throw std::runtime_error("poisson: dataCost must be > 0 for the CG solver");
+    if (solver != GDPT_SOLVER_CG) throw std::runtime_error("poisson: only GDPT_SOLVER_CG is built in this round");
+    if (tol <= 0) tol = 1e-10;
+    if (max_iters <= 0) max_iters = 2000;
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    gp::Geo g{w, h, w * h * 3, w * 3};
+    g_ws.ensure((size_t)g.n3);
+    Workspace &ws = g_ws;
+    const int nb = std::min(gp::kMaxBlocks, (g.n3 + gp::kBlock - 1) / gp::kBlock);
+    // init layout: 8 slots of nb doubles (slot 0 = <r,r>, reused as part_rr); <p,q> partials live in slot 8
+    double *part_rr = ws.partials, *part_pq = ws.partials + 8 * (size_t)nb;
+    hipEvent_t e0, e1;
+    ck(hipEventCreate(&e0), "hipEventCreate"); ck(hipEventCreate(&e1), "hipEventCreate");
+    ck(hipEventRecord(e0, stream), "hipEventRecord");
+    hipLaunchKernelGGL(gp::cg_init_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, alpha, d_c, d_gx, d_gy, ws.x, ws.r, ws.p0, ws.p1, ws.partials);
+    hipLaunchKernelGGL(gp::cg_init_reduce_kernel, dim3(1), dim3(gp::kBlock), 0, stream, nb, ws.partials, ws.state, tol);
+    ck(hipGetLastError(), "cg init launch");
+    const int chunk = 32;          // even, so buffer parity is chunk-invariant
+    int launched = 0;
+    bool done = false;
+    // one chunk is always in flight ahead of the status check of the previous one (no pipeline bubble)
+    auto enqueue_chunk = [&]() {
+        for (int k = 0; k < chunk; k++) {
+            int it = launched + k;
+            const double *pin = (it & 1) ? ws.p1 : ws.p0;
+            double *pout = (it & 1) ? ws.p0 : ws.p1;
+            hipLaunchKernelGGL(gp::cg_step_a, dim3(nb), dim3(gp::kBlock), 0, stream, g, alpha, it, ws.r, pin, pout, ws.q, part_rr, part_pq, ws.state);
+            hipLaunchKernelGGL(gp::cg_step_b, dim3(nb), dim3(gp::kBlock), 0, stream, g, it, pout, ws.q, ws.x, ws.r, part_pq, part_rr, ws.state);
+        }
+        launched += chunk;
+        ck(hipGetLastError(), "cg chunk launch");
+    };
+    hipEvent_t chunk_ev;
+    ck(hipEventCreate(&chunk_ev), "hipEventCreate");
+    enqueue_chunk();
+    while (!done) {
+        ck(hipMemcpyAsync(ws.h_state, ws.state, sizeof(gp::CgState), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(state)");
+        ck(hipEventRecord(chunk_ev, stream), "hipEventRecord");
+        bool more = launched < max_iters;
+        if (more) enqueue_chunk();               // speculative next chunk; its kernels exit at once if converged
+        ck(hipEventSynchronize(chunk_ev), "hipEventSynchronize");
+        if (ws.h_state->converged || !more) done = true;
+    }
+    hipLaunchKernelGGL(gp::cg_finalize_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, alpha, ws.x, d_out, part_rr, nb, ws.state, ws.rel);
+    ck(hipGetLastError(), "cg finalize launch");
+    ck(hipMemcpyAsync(ws.h_state, ws.state, sizeof(gp::CgState), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(state)");
+    ck(hipMemcpyAsync(ws.h_rel, ws.rel, sizeof(double), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(rel)");
+    ck(hipEventRecord(e1, stream), "hipEventRecord");
+    ck(hipEventSynchronize(e1), "hipEventSynchronize");
+    float ms = 0;
+    ck(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(chunk_ev);
+    PoissonResult res;
+    res.iterations = ws.h_state->iters; res.solver = GDPT_SOLVER_CG; res.rel_residual = *ws.h_rel; res.solve_ms = ms;
+    return res;
+}
+
+} // namespace gdpt

@@ -1,0 +1,185 @@
+// bvh.cpp — binned-SAH BVH2 with a hard depth bound (so the GPU traversal stack, one LDS slot
+// per level per lane, can never overflow).
+#include "bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace gdpt {
+
+namespace {
+
+struct Box {
+    float mn[3], mx[3];
+    void reset() {
+        for (int k = 0; k < 3; k++) { mn[k] = std::numeric_limits<float>::infinity(); mx[k] = -std::numeric_limits<float>::infinity(); }
+    }
+    void grow(const float *a, const float *b) {
+        for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], a[k]); mx[k] = std::max(mx[k], b[k]); }
+    }
+    void grow(const Box &o) { grow(o.mn, o.mx); }
+    void grow_pt(const float *p) { grow(p, p); }
+    float half_area() const {
+        float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        if (!(dx >= 0 && dy >= 0 && dz >= 0)) return 0.f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Builder {
+    const std::vector<PrimBounds> &pb;
+    std::vector<uint32_t> idx;       // working permutation
+    std::vector<float> cent;         // 3 per prim
+    BvhBuildResult out;
+
+    explicit Builder(const std::vector<PrimBounds> &b) : pb(b) {}
+
+    static int ceil_log2(uint32_t n) { int l = 0; while ((1u << l) < n) l++; return l; }
+
+    Box range_box(uint32_t b, uint32_t e) const {
+        Box bx; bx.reset();
+        for (uint32_t i = b; i < e; i++) bx.grow(pb[idx[i]].bmin, pb[idx[i]].bmax);
+        return bx;
+    }
+
+    int32_t make_leaf(uint32_t b, uint32_t e) {
+        uint32_t first = (uint32_t)out.order.size();
+        for (uint32_t i = b; i < e; i++) out.order.push_back(idx[i]);
+        uint32_t packed = (first << 2) | (e - b - 1);
+        return ~(int32_t)packed;
+    }
+
+    // Returns the split position in [b+1, e-1]; reorders idx[b,e).
+    uint32_t split(uint32_t b, uint32_t e, bool force_median) {
+        uint32_t n = e - b;
+        Box cb; cb.reset();
+        for (uint32_t i = b; i < e; i++) cb.grow_pt(&cent[3 * idx[i]]);
+        int best_axis = -1; int best_bin = -1; float best_cost = std::numeric_limits<float>::infinity();
+        constexpr int NB = 32;
+        if (!force_median) {
+            for (int ax = 0; ax < 3; ax++) {
+                float lo = cb.mn[ax], hi = cb.mx[ax];
+                if (!(hi > lo)) continue;
+                Box bb[NB]; uint32_t cnt[NB];
+                for (int k = 0; k < NB; k++) { bb[k].reset(); cnt[k] = 0; }
+                float scale = NB / (hi - lo);
+                for (uint32_t i = b; i < e; i++) {
+                    int k = (int)((cent[3 * idx[i] + ax] - lo) * scale);
+                    k = std::min(std::max(k, 0), NB - 1);
+                    bb[k].grow(pb[idx[i]].bmin, pb[idx[i]].bmax); cnt[k]++;
+                }
+                float right_area[NB]; uint32_t right_cnt[NB];
+                Box acc; acc.reset(); uint32_t c = 0;
+                for (int k = NB - 1; k > 0; k--) { acc.grow(bb[k]); c += cnt[k]; right_area[k] = acc.half_area(); right_cnt[k] = c; }
+                acc.reset(); c = 0;
+                for (int k = 0; k < NB - 1; k++) {
+                    acc.grow(bb[k]); c += cnt[k];
+                    if (c == 0 || right_cnt[k + 1] == 0) continue;
+                    float cost = acc.half_area() * (float)c + right_area[k + 1] * (float)right_cnt[k + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = k; }
+                }
+            }
+        }
+        if (best_axis >= 0) {
+            float lo = cb.mn[best_axis], hi = cb.mx[best_axis];
+            float scale = NB / (hi - lo);
+            auto mid = std::partition(idx.begin() + b, idx.begin() + e, [&](uint32_t p) {
+                int k = (int)((cent[3 * p + best_axis] - lo) * scale);
+                k = std::min(std::max(k, 0), NB - 1);
+                return k <= best_bin;
+            });
+            uint32_t m = (uint32_t)(mid - idx.begin());
+            if (m > b && m < e) return m;
+        }
+        // median split along the widest centroid axis (also the depth-bounding fallback)
+        int ax = 0;
+        float ext = -1;
+        for (int k = 0; k < 3; k++) { float d = cb.mx[k] - cb.mn[k]; if (d > ext) { ext = d; ax = k; } }
+        uint32_t m = b + n / 2;
+        std::nth_element(idx.begin() + b, idx.begin() + m, idx.begin() + e,
+                         [&](uint32_t p, uint32_t q) { return cent[3 * p + ax] < cent[3 * q + ax]; });
+        return m;
+    }
+
+    // Builds the subtree over idx[b,e) (n > LEAF_MAX or forced inner) and returns its node index.
+    // `level` = number of inner nodes above this one.
+    int32_t build_inner(uint32_t b, uint32_t e, int level, int *depth_out) {
+        int32_t me = (int32_t)out.nodes.size();
+        out.nodes.emplace_back();
+        uint32_t n = e - b;
+        // Levels still available below this node, and levels a balanced tree over n prims needs.
+        int remaining = GDPT_BVH_MAX_DEPTH - (level + 1);
+        int need_balanced = std::max(0, ceil_log2((n + GDPT_LEAF_MAX_PRIMS - 1) / GDPT_LEAF_MAX_PRIMS));
+        bool force_median = (need_balanced >= remaining);
+        uint32_t m = split(b, e, force_median);
+        int dl = 0, dr = 0;
+        int32_t cl = build_child(b, m, level + 1, &dl);
+        int32_t cr = build_child(m, e, level + 1, &dr);
+        Box lb = range_box(b, m), rb = range_box(m, e);
+        DevBvhNode &nd = out.nodes[(size_t)me];
+        for (int k = 0; k < 3; k++) { nd.lmin[k] = lb.mn[k]; nd.lmax[k] = lb.mx[k]; nd.rmin[k] = rb.mn[k]; nd.rmax[k] = rb.mx[k]; }
+        nd.left = cl; nd.right = cr; nd.pad[0] = nd.pad[1] = 0;
+        *depth_out = 1 + std::max(dl, dr);
+        return me;
+    }
+
+    int32_t build_child(uint32_t b, uint32_t e, int level, int *depth_out) {
+        uint32_t n = e - b;
+        if (n <= GDPT_LEAF_MAX_PRIMS) {
+            // SAH leaf test for small ranges: keep splitting only if it pays (cost model: 1 per prim, 1 per node)
+            bool make = true;
+            if (n > 1 && level < GDPT_BVH_MAX_DEPTH) {
+                Box full = range_box(b, e);
+                float fa = full.half_area();
+                if (fa > 0) {
+                    // try the best object split along the widest axis
+                    std::vector<uint32_t> save(idx.begin() + b, idx.begin() + e);
+                    uint32_t m = split(b, e, false);
+                    float cost = (range_box(b, m).half_area() * (float)(m - b) + range_box(m, e).half_area() * (float)(e - m)) / fa + 1.0f;
+                    if (cost < (float)n * 0.8f) {
+                        make = false;
+                    } else {
+                        std::copy(save.begin(), save.end(), idx.begin() + b);
+                    }
+                }
+            }
+            if (make) { *depth_out = 0; return make_leaf(b, e); }
+        }
+        return build_inner(b, e, level, depth_out);
+    }
+};
+
+} // namespace
+
+BvhBuildResult build_bvh(const std::vector<PrimBounds> &bounds) {
+    Builder bld(bounds);
+    uint32_t n = (uint32_t)bounds.size();
+    if (n == 0) return std::move(bld.out);
+    bld.idx.resize(n);
+    bld.cent.resize(3 * (size_t)n);
+    for (uint32_t i = 0; i < n; i++) {
+        bld.idx[i] = i;
+        for (int k = 0; k < 3; k++) bld.cent[3 * (size_t)i + k] = 0.5f * bounds[i].bmin[k] + 0.5f * bounds[i].bmax[k];
+    }
+    bld.out.order.reserve(n);
+    bld.out.nodes.reserve(n);
+    if (n <= 1) {
+        // degenerate root: one leaf on the left, nothing on the right
+        bld.out.nodes.emplace_back();
+        DevBvhNode &nd = bld.out.nodes[0];
+        for (int k = 0; k < 3; k++) {
+            nd.lmin[k] = bounds[0].bmin[k]; nd.lmax[k] = bounds[0].bmax[k];
+            nd.rmin[k] = std::numeric_limits<float>::infinity(); nd.rmax[k] = -std::numeric_limits<float>::infinity();
+        }
+        nd.left = bld.make_leaf(0, 1); nd.right = GDPT_CHILD_EMPTY; nd.pad[0] = nd.pad[1] = 0;
+        bld.out.depth = 1;
+        return std::move(bld.out);
+    }
+    int depth = 0;
+    bld.build_inner(0, n, 0, &depth);
+    bld.out.depth = depth;
+    return std::move(bld.out);
+}
+
+} // namespace gdpt

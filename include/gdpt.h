@@ -1,0 +1,224 @@
+/* gdpt.h — C ABI of the MI355X-native gradient-domain path tracing hot path.
+ *
+ * This is the drop-in boundary for LaJolla's `Integrator::GradPath` path
+ * (reference: vedrocks15/Gradient-Based-Path-Tracing). The reference has no FFI
+ * layer; its seams are C++ functions linked statically. Each entry point below
+ * names the reference interface it replaces (file:line under /root/reference).
+ *
+ *   gdpt_parse_scene        <- parse_scene()            src/parsers/parse_scene.h:9, parse_scene.cpp:1615-1630
+ *   gdpt_scene_upload       <- Scene::Scene()           src/scene.cpp:4-53   (Embree BVH build -> own BVH2 + HBM upload)
+ *   gdpt_render             <- gradient_path_render()   src/render.cpp:257-333 (tile loop + grad_path_tracing, src/path_tracing.h:354-1050)
+ *   gdpt_assemble           <- gradient assembly        src/render.cpp:336-350
+ *   gdpt_poisson_solve      <- fourierSolve()           src/render.cpp:172-254 (argument-for-argument)
+ *   gdpt_gradient_path_render <- gradient_path_render() src/render.cpp:257-370 (whole: render + assemble + solve)
+ *   gdpt_imwrite            <- imwrite()                src/image.cpp:135-173
+ *
+ * Plain pointers and sizes only; no C++/torch types. All images are row-major
+ * `data[(y*W+x)*3+c]` fp64, exactly `Image3::data` (src/image.h:13-39).
+ * Every function returns 0 on success, non-zero on failure; the message is
+ * available from gdpt_last_error() (thread-local).
+ */
+#ifndef GDPT_H
+#define GDPT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- scene description (host memory, flattened `Scene`, src/scene.h:40-80) ---- */
+
+enum { GDPT_TEX_CONSTANT = 0, GDPT_TEX_IMAGE = 1, GDPT_TEX_CHECKERBOARD = 2 }; /* src/texture.h:83-102 */
+
+/* Texture<Real> uses v0[0]/v1[0]; Texture<Spectrum> uses all three channels. */
+typedef struct GdptTexture {
+    int32_t type;
+    int32_t image_id;         /* IMAGE: index into GdptSceneDesc::images (1- or 3-channel) */
+    double v0[3];             /* CONSTANT: value; CHECKERBOARD: color0 */
+    double v1[3];             /* CHECKERBOARD: color1 */
+    double uscale, vscale, uoffset, voffset;
+} GdptTexture;
+
+/* Order follows the std::variant in src/material.h:82-90. */
+enum {
+    GDPT_MAT_LAMBERTIAN = 0, GDPT_MAT_ROUGHPLASTIC = 1, GDPT_MAT_ROUGHDIELECTRIC = 2,
+    GDPT_MAT_DISNEY_DIFFUSE = 3, GDPT_MAT_DISNEY_METAL = 4, GDPT_MAT_DISNEY_GLASS = 5,
+    GDPT_MAT_DISNEY_CLEARCOAT = 6, GDPT_MAT_DISNEY_SHEEN = 7, GDPT_MAT_DISNEY_BSDF = 8
+};
+
+/* Texture slots per material type (member order of the structs in src/material.h:12-80):
+ *   LAMBERTIAN       0 reflectance
+ *   DISNEY_DIFFUSE   0 base_color 1 roughness 2 subsurface
+ *   DISNEY_METAL     0 base_color 1 roughness 2 anisotropic
+ *   DISNEY_GLASS     0 base_color 1 roughness 2 anisotropic            (+eta)
+ *   DISNEY_CLEARCOAT 0 clearcoat_gloss
+ *   DISNEY_SHEEN     0 base_color 1 sheen_tint
+ *   DISNEY_BSDF      0 base_color 1 specular_transmission 2 metallic 3 subsurface 4 specular
+ *                    5 roughness 6 specular_tint 7 anisotropic 8 sheen 9 sheen_tint
+ *                    10 clearcoat 11 clearcoat_gloss                    (+eta)
+ */
+#define GDPT_MAT_MAX_TEX 12
+typedef struct GdptMaterial {
+    int32_t type;
+    int32_t _pad;
+    double eta;
+    GdptTexture tex[GDPT_MAT_MAX_TEX];
+} GdptMaterial;
+
+typedef struct GdptImage {     /* level 0 of a Mipmap1/Mipmap3 (src/mipmap.h:9-12); mips are built by the library */
+    int32_t width, height, channels; /* channels 1 or 3 */
+    int32_t _pad;
+    const double *texels;      /* width*height*channels, row-major */
+} GdptImage;
+
+enum { GDPT_SHAPE_SPHERE = 0, GDPT_SHAPE_TRIMESH = 1 }; /* src/shape.h:44 */
+
+typedef struct GdptShape {
+    int32_t type;
+    int32_t material_id;
+    int32_t area_light_id;     /* -1 if not an emitter */
+    int32_t num_vertices, num_triangles;
+    int32_t _pad;
+    double center[3];          /* sphere */
+    double radius;             /* sphere */
+    const double *positions;   /* 3*num_vertices (world space) */
+    const int32_t *indices;    /* 3*num_triangles */
+    const double *normals;     /* 3*num_vertices or NULL */
+    const double *uvs;         /* 2*num_vertices or NULL */
+} GdptShape;
+
+typedef struct GdptLight {     /* DiffuseAreaLight, src/light.h; envmaps are ignored by GradPath (src/path_tracing.h:982-985) */
+    int32_t shape_id;
+    int32_t _pad;
+    double intensity[3];
+} GdptLight;
+
+enum { GDPT_FILTER_BOX = 0, GDPT_FILTER_TENT = 1, GDPT_FILTER_GAUSSIAN = 2 }; /* src/filter.h:31-46 */
+
+typedef struct GdptCamera {    /* src/camera.h:10-26 */
+    double sample_to_cam[16];  /* row-major 4x4 */
+    double cam_to_world[16];
+    int32_t width, height;
+    int32_t filter_type;
+    int32_t _pad;
+    double filter_param;       /* Box/Tent: width; Gaussian: stddev */
+} GdptCamera;
+
+enum { GDPT_INTEGRATOR_PATH = 5, GDPT_INTEGRATOR_GRADPATH = 7, GDPT_INTEGRATOR_OTHER = -1 }; /* src/scene.h:14-23 */
+
+typedef struct GdptSceneDesc {
+    GdptCamera camera;
+    int32_t integrator;
+    int32_t samples_per_pixel; /* <sampler sampleCount>; the reference ignores it (src/render.cpp:293) */
+    int32_t max_depth;         /* -1 = unbounded (RR only) */
+    int32_t rr_depth;
+    int32_t num_materials, num_shapes, num_lights, num_images;
+    const GdptMaterial *materials;
+    const GdptShape *shapes;
+    const GdptLight *lights;
+    const GdptImage *images;
+    char output_filename[256]; /* film `filename`, default "image.exr" (src/parsers/parse_scene.cpp:15) */
+} GdptSceneDesc;
+
+/* ---- render parameters ---- */
+
+/* How PCG32 streams (src/pcg.h:33-41) are assigned.
+ *   TILE   : init_pcg32(tile_y*ntx+tile_x), pixels y-outer/x-inner, samples innermost — bit-for-bit the
+ *            reference order (src/render.cpp:281-309). Serial per tile: one GPU lane per tile (slow; for checks).
+ *   SAMPLE : init_pcg32((y*W+x)*spp + s) per sample — every sample independent (the throughput mode). */
+enum { GDPT_RNG_TILE = 0, GDPT_RNG_SAMPLE = 2 };
+
+typedef struct GdptRenderParams {
+    int32_t spp;               /* <=0: use scene samples_per_pixel; the reference hard-codes 1000 (src/render.cpp:293) */
+    int32_t rng_scheme;        /* GDPT_RNG_* */
+    int32_t row_begin, row_end;/* render rows [row_begin,row_end) only (multi-GPU bands); 0,0 = whole image.
+                                  Rows outside the band are left untouched in the output buffers. */
+    int32_t max_depth_override;/* 0 = use scene; else value */
+    int32_t _pad;
+} GdptRenderParams;
+
+typedef struct GdptRenderStats {
+    uint64_t samples;          /* grad_path_tracing calls */
+    uint64_t rays;             /* closest-hit queries (5 primaries + 1 per bounce; the reference's 4 tfar=0 rays are omitted) */
+    uint64_t bounces;          /* bounce-loop iterations */
+    uint64_t nodes_visited;    /* BVH nodes fetched (counting builds only, else 0) */
+    uint64_t tris_tested;      /* triangles tested (counting builds only, else 0) */
+    uint64_t nonfinite_samples;/* samples whose record held a NaN/Inf (propagated, as the reference does) */
+    double render_ms;          /* device time of the render kernel(s), HIP events */
+} GdptRenderStats;
+
+typedef struct GdptPoissonStats {
+    int32_t iterations;        /* CG iterations (0 for the direct DCT solver) */
+    int32_t solver;            /* GDPT_SOLVER_* actually used */
+    double rel_residual;       /* ||W(h - A f)|| / ||W h|| at exit (CG) */
+    double solve_ms;           /* device time, HIP events */
+} GdptPoissonStats;
+
+enum { GDPT_SOLVER_CG = 0, GDPT_SOLVER_DCT = 1 };
+
+typedef struct GdptScene GdptScene;   /* opaque: device-resident scene (BVH2, triangles, materials, textures) */
+
+/* ---- host-side scene ingest (Mitsuba-0.x XML subset) ---- */
+int gdpt_parse_scene(const char *xml_path, GdptSceneDesc **out_desc);
+void gdpt_free_scene_desc(GdptSceneDesc *desc);
+
+/* ---- device scene ---- */
+int gdpt_scene_upload(const GdptSceneDesc *desc, int device, GdptScene **out_scene);
+void gdpt_scene_free(GdptScene *scene);
+/* Copies the BVH the library built (for inspection/tests): node count, triangle count, depth. */
+int gdpt_scene_info(const GdptScene *scene, int32_t *num_nodes, int32_t *num_tris, int32_t *num_spheres, int32_t *bvh_depth);
+
+/* ---- hot path, host buffers (caller-owned W*H*3 doubles each, as Image3::data) ---- */
+int gdpt_render(GdptScene *scene, const GdptRenderParams *params,
+                double *img, double *cx0, double *cy0, double *cx1, double *cy1,
+                GdptRenderStats *stats /* nullable */);
+
+/* ---- hot path, device buffers (hipMalloc'd / torch CUDA tensors; data stays in HBM) ----
+ * `stream` is a hipStream_t passed as void* (NULL = default stream). Asynchronous w.r.t. the host
+ * unless `stats` is non-NULL (then it synchronises to read the counters). */
+int gdpt_render_device(GdptScene *scene, const GdptRenderParams *params,
+                       double *d_img, double *d_cx0, double *d_cy0, double *d_cx1, double *d_cy1,
+                       void *stream, GdptRenderStats *stats /* nullable */);
+
+/* c=img; cx=cx0(x,y)+cx1(x-1,y); cy=cy0(x,y)+cy1(x,y-1)  (src/render.cpp:340-350). Device pointers. */
+int gdpt_assemble_device(int width, int height,
+                         const double *d_img, const double *d_cx0, const double *d_cy0,
+                         const double *d_cx1, const double *d_cy1,
+                         double *d_c, double *d_cx, double *d_cy, void *stream);
+
+/* Screened Poisson reconstruction; same arguments as fourierSolve (src/render.cpp:172-175). Host pointers. */
+int gdpt_poisson_solve(int width, int height,
+                       const double *imgData, const double *imgGradX, const double *imgGradY,
+                       double dataCost, double *imgOut);
+/* Same with solver choice, tolerance and stats. solver: GDPT_SOLVER_*. tol<=0 selects the default 1e-10. */
+int gdpt_poisson_solve_ex(int width, int height,
+                          const double *imgData, const double *imgGradX, const double *imgGradY,
+                          double dataCost, double *imgOut,
+                          int solver, double tol, int max_iters, GdptPoissonStats *stats /* nullable */);
+/* Device-pointer variant (inputs/outputs in HBM). `workspace` may be NULL (the library keeps a cached one). */
+int gdpt_poisson_solve_device(int width, int height,
+                              const double *d_c, const double *d_gx, const double *d_gy,
+                              double dataCost, double *d_out,
+                              int solver, double tol, int max_iters,
+                              void *stream, GdptPoissonStats *stats /* nullable */);
+
+/* Whole Integrator::GradPath: render -> assemble -> solve -> final image (host, W*H*3 doubles).
+ * Optionally returns the five raw buffers too (any of them may be NULL). */
+int gdpt_gradient_path_render(GdptScene *scene, const GdptRenderParams *params, double dataCost,
+                              double *out_image,
+                              double *img, double *cx0, double *cy0, double *cx1, double *cy1,
+                              GdptRenderStats *rstats, GdptPoissonStats *pstats);
+
+/* ---- output ---- */
+/* By suffix: ".pfm" (fp32, header "PF\nW H\n-1\n", rows as stored) or ".exr" (fp16 RGB scanline). */
+int gdpt_imwrite(const char *filename, int width, int height, const double *rgb);
+
+const char *gdpt_last_error(void);
+/* "gfx950" etc. of the device the library's kernels were built for, and the running device name. */
+const char *gdpt_build_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDPT_H */
