@@ -15,7 +15,7 @@ struct Hit { float t, u, v, ngx, ngy, ngz; int gid; };   // gid < 0: miss
 struct TraceCounters { unsigned long long nodes, prims; };
 
 // fp32 Moller-Trumbore, two-sided; every operation rounds once (no FMA contraction), sums left to right.
-// Bit-for-bit the oracle's tri_hit (oracle/oracle.cpp).
+// The CPU checker used by the tests restates exactly this arithmetic.
 GD bool tri_hit(const float o[3], const float d[3], float tnear, float tfar, const DevPrim &tr, float &t, float &u, float &v) {
 #pragma clang fp contract(off)
     const float *e1 = tr.e1, *e2 = tr.e2;

@@ -1,0 +1,94 @@
+// lajolla_main.cpp — drop-in `./lajolla [-t num_threads] [-o output_file_name] filename.xml` for the
+// GradPath path (reference CLI: src/main.cpp:11-51). Host C++ over the C ABI in include/gdpt.h.
+//
+// Same flags, same stdout lines ("Parsing and constructing scene ...", "Done. Took X seconds.",
+// "Rendering...", "Image written to ..."), same output-name quirk (with several scenes the first
+// scene's name sticks, src/main.cpp:42). Extra flags, because the reference hard-codes them:
+//   --spp N       samples per pixel (default: the scene's <sampler sampleCount>)
+//   --ref-spp     the reference's hard-coded 1000 spp (src/render.cpp:293)
+//   --rng tile|sample   PCG stream assignment (default sample; tile = the reference's order, slow)
+//   --alpha A     Poisson data weight (default 0.04, src/render.cpp:353)
+//   --device D    GPU index
+// `-t` is accepted for compatibility; rendering runs on the GPU, so it has no effect.
+#include "../../include/gdpt.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <vector>
+
+int main(int argc, char *argv[]) {
+    if (argc <= 1) {
+        std::cout << "[Usage] ./lajolla [-t num_threads] [-o output_file_name] filename.xml" << std::endl;
+        return 0;
+    }
+    int num_threads = 0, spp = 0, device = 0, rng = GDPT_RNG_SAMPLE;
+    double alpha = 0.04;
+    std::string outputfile = "";
+    std::vector<std::string> filenames;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&]() -> std::string { if (i + 1 >= argc) { std::cerr << "missing value for " << a << std::endl; std::exit(2); } return argv[++i]; };
+        if (a == "-t") num_threads = std::stoi(next());
+        else if (a == "-o") outputfile = next();
+        else if (a == "--spp") spp = std::stoi(next());
+        else if (a == "--ref-spp") spp = 1000;
+        else if (a == "--alpha") alpha = std::stod(next());
+        else if (a == "--device") device = std::stoi(next());
+        else if (a == "--rng") { std::string v = next(); rng = (v == "tile") ? GDPT_RNG_TILE : GDPT_RNG_SAMPLE; }
+        else filenames.push_back(a);
+    }
+    (void)num_threads;
+
+    using clock = std::chrono::system_clock;
+    for (const std::string &filename : filenames) {
+        auto t0 = clock::now();
+        std::cout << "Parsing and constructing scene " << filename << "." << std::endl;
+        GdptSceneDesc *desc = nullptr;
+        if (gdpt_parse_scene(filename.c_str(), &desc) != 0) {
+            std::cerr << "terminate: " << gdpt_last_error() << std::endl;   // the reference dies on an uncaught fl_exception
+            return 134;
+        }
+        if (desc->integrator != GDPT_INTEGRATOR_GRADPATH) {
+            std::cerr << "terminate: this build implements Integrator::GradPath only (scene asks for another integrator)" << std::endl;
+            return 134;
+        }
+        GdptScene *scene = nullptr;
+        if (gdpt_scene_upload(desc, device, &scene) != 0) {
+            std::cerr << "terminate: " << gdpt_last_error() << std::endl;
+            return 134;
+        }
+        auto t1 = clock::now();
+        std::cout << "Done. Took " << std::chrono::duration<double>(t1 - t0).count() << " seconds." << std::endl;
+        std::cout << "Rendering..." << std::endl;
+        const int w = desc->camera.width, h = desc->camera.height;
+        std::vector<double> image((size_t)w * h * 3);
+        GdptRenderParams p{};
+        p.spp = spp; p.rng_scheme = rng;
+        GdptRenderStats rs{};
+        GdptPoissonStats ps{};
+        if (gdpt_gradient_path_render(scene, &p, alpha, image.data(), nullptr, nullptr, nullptr, nullptr, nullptr, &rs, &ps) != 0) {
+            std::cerr << "terminate: " << gdpt_last_error() << std::endl;
+            return 134;
+        }
+        // the reference prints one progress line per finished tile and a final 100% line (src/progress_reporter.h:22-29)
+        unsigned long long tiles = (unsigned long long)((w + 15) / 16) * ((h + 15) / 16);
+        std::fprintf(stdout, "\r %.2f Percent Done (%llu / %llu)\n", 100.0, tiles, tiles);
+        if (outputfile.compare("") == 0) outputfile = desc->output_filename;
+        auto t2 = clock::now();
+        std::cout << "Done. Took " << std::chrono::duration<double>(t2 - t1).count() << " seconds." << std::endl;
+        if (gdpt_imwrite(outputfile.c_str(), w, h, image.data()) != 0) {
+            std::cerr << "terminate: " << gdpt_last_error() << std::endl;
+            return 134;
+        }
+        std::cout << "Image written to " << outputfile << std::endl;
+        std::cout << "[gdpt] " << rs.samples << " samples, " << rs.rays << " rays, render " << rs.render_ms << " ms ("
+                  << (rs.render_ms > 0 ? rs.samples / rs.render_ms / 1e3 : 0.0) << " Msamples/s), Poisson " << ps.iterations
+                  << " CG iterations " << ps.solve_ms << " ms, non-finite samples " << rs.nonfinite_samples << std::endl;
+        gdpt_scene_free(scene);
+        gdpt_free_scene_desc(desc);
+    }
+    return 0;
+}
