@@ -146,7 +146,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_py as O
-        cores = os.cpu_count() or 1
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
         osc = O.OracleScene(sd.ptr, use_bvh=True)
         ob, ost = osc.render(args.cpu_spp, G.RNG_TILE, threads=cores)
         tp = time.perf_counter()

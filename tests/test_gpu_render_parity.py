@@ -122,7 +122,7 @@ def test_textured_two_sided_synthetic_scene(G, O):
     b.mesh(pos, idx, m_glass)
     pos, idx = quad([[0.4, 0.1, -0.5], [1.8, 0.1, -0.2], [1.8, 1.4, -0.2], [0.4, 1.4, -0.5]])
     b.mesh(pos, idx, m_bsdf, uvs=[0, 0, 1, 0, 1, 1, 0, 1])
-    pos, idx = quad([[-1, 3, -1], [-1, 3, 1], [1, 3, 1], [1, 3, -1]])
+    pos, idx = quad([[-1, 3, -1], [1, 3, -1], [1, 3, 1], [-1, 3, 1]])     # wound to face down (-y)
     b.mesh(pos, idx, m_light, light=(12.0, 10.0, 8.0))
     b.sphere((-1.5, 0.6, -1.0), 0.6, m_bsdf)
     # camera: reuse the loader's camera maths through a tiny scene file is overkill; look down -z from (0,1.2,5)
