@@ -29,11 +29,17 @@ struct DevPrim {
     uint32_t pad[2];
 };
 
-// fp64 per-triangle shading inputs (compute_shading_info, src/shapes/triangle_mesh.inl:77-169), 216 B.
+// fp64 per-triangle shading inputs (compute_shading_info, src/shapes/triangle_mesh.inl:77-169), 232 B.
+// Everything that does not depend on the hit point is evaluated once on the host with the reference's formulas
+// (same operation order, no FMA contraction): dp/du, dp/dv (:108-131), max(|dpdu|,|dpdv|) (:168) and the
+// normalised fp32-cross-product geometric normal that intersect() derives from Embree's Ng
+// (src/intersection.cpp:41). `degenerate_uv` marks |det| <= 1e-8f, where dpdu/dpdv hold coordinate_system(gn).
 struct DevTriShade {
-    double p[3][3];
     double n[3][3];      // vertex normals (has_normals)
     double uv[3][2];     // vertex uvs (has_uvs), else the reference's default (0,0),(1,0),(1,1)
+    double dpdu[3], dpdv[3];
+    double gn[3];        // normalize(fp64(e1 x e2 in fp32))
+    double inv_uv_size;
     int32_t shape_id, prim_id, material_id, light_id; // light_id < 0: not an emitter
     int32_t has_normals, has_uvs;
 };
@@ -73,6 +79,6 @@ struct DevSceneView {
     int32_t num_nodes, num_prims, num_tris, num_spheres;
     int32_t num_materials, num_lights, num_images;
     int32_t max_depth, rr_depth;
-    int32_t all_lambert_const;              // every material is Lambertian with a constant reflectance
+    int32_t all_textures_constant;          // no image / checkerboard texture anywhere: uv and footprints are unobservable
     double isect_eps;                       // get_intersection_epsilon, src/scene.h:100-102
 };

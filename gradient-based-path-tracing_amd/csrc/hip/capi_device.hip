@@ -4,6 +4,7 @@
 #include "../capi_common.h"
 #include "../device_scene.h"
 #include "../host/bvh.h"
+#include "../host/tri_precompute.h"
 #include "poisson_kernels.h"
 #include "render_kernels.h"
 
@@ -11,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -39,6 +41,7 @@ struct GdptScene {
     DevSceneView view{};
     int bvh_depth = 0;
     int scene_spp = 0;             // <sampler sampleCount> of the description (default spp)
+    bool one_sided = true, lambert_only = true;
     std::vector<void *> allocations;
     // cached output/work buffers for the host-pointer entry points
     double *d_buf[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -112,12 +115,13 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
             DevPrim pr{};
             gdpt::PrimBounds pb;
             float v[3][3];
+            double pos64[3][3];
             for (int k = 0; k < 3; k++) { pb.bmin[k] = std::numeric_limits<float>::infinity(); pb.bmax[k] = -pb.bmin[k]; }
             for (int i = 0; i < 3; i++) {
                 int vi = sh.indices[3 * t + i];
                 if (vi < 0 || vi >= sh.num_vertices) throw std::runtime_error("gdpt_scene_upload: mesh index out of range");
                 for (int k = 0; k < 3; k++) {
-                    ts.p[i][k] = sh.positions[3 * vi + k];
+                    pos64[i][k] = sh.positions[3 * vi + k];
                     v[i][k] = (float)sh.positions[3 * vi + k];
                     pb.bmin[k] = std::min(pb.bmin[k], v[i][k]); pb.bmax[k] = std::max(pb.bmax[k], v[i][k]);
                     if (sh.normals) ts.n[i][k] = sh.normals[3 * vi + k];
@@ -130,6 +134,7 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
             ts.shape_id = s; ts.prim_id = t; ts.material_id = sh.material_id; ts.light_id = sh.area_light_id;
             ts.has_normals = sh.normals != nullptr; ts.has_uvs = sh.uvs != nullptr;
             for (int k = 0; k < 3; k++) { pr.v0[k] = v[0][k]; pr.e1[k] = v[1][k] - v[0][k]; pr.e2[k] = v[2][k] - v[0][k]; }
+            gdpt::precompute_tri_constants(pos64, pr.e1, pr.e2, &ts);
             pr.gid = (uint32_t)tris.size();
             tris.push_back(ts); prim_in.push_back(pr); bounds.push_back(pb);
         }
@@ -215,8 +220,12 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     v.num_tris = (int)tris.size(); v.num_spheres = (int)spheres.size();
     v.num_materials = desc->num_materials; v.num_lights = desc->num_lights; v.num_images = desc->num_images;
     v.max_depth = desc->max_depth; v.rr_depth = desc->rr_depth;
-    v.all_lambert_const = 1;
-    for (auto &m : materials) if (m.type != GDPT_MAT_LAMBERTIAN || m.tex[0].type != GDPT_TEX_CONSTANT) v.all_lambert_const = 0;
+    v.all_textures_constant = 1;
+    for (auto &m : materials) for (auto &t : m.tex) if (t.type != GDPT_TEX_CONSTANT) v.all_textures_constant = 0;
+    for (auto &m : materials) {
+        if (m.type != GDPT_MAT_LAMBERTIAN) sc->lambert_only = false;
+        if (m.type == GDPT_MAT_DISNEY_GLASS || m.type == GDPT_MAT_DISNEY_BSDF) sc->one_sided = false;   // two-sided lobes
+    }
     // get_intersection_epsilon (src/scene.h:100-102) from Embree-style fp32 scene bounds (src/scene.cpp:29-33)
     double dx = (double)ub[0] - (double)lb[0], dy = (double)ub[1] - (double)lb[1], dz = (double)ub[2] - (double)lb[2];
     double radius = prims.empty() ? 0.0 : std::sqrt(dx * dx + dy * dy + dz * dz) / 2;
@@ -260,6 +269,14 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.img = img; rl.cx0 = cx0; rl.cy0 = cy0; rl.cx1 = cx1; rl.cy1 = cy1;
     rl.counters = sc->d_counters;
     rl.count_traversal = stats && stats->nodes_visited == ~0ull;   // request flag: caller presets nodes_visited = UINT64_MAX
+    rl.one_sided_materials = sc->one_sided; rl.lambert_only = sc->lambert_only;
+    rl.scene_fits_lds = gdpt::scene_fits_lds(sc->view.num_nodes, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->bvh_depth);
+    auto env_int = [](const char *name, int def) { const char *v = std::getenv(name); return v ? std::atoi(v) : def; };
+    rl.force_eager = env_int("GDPT_FORCE_EAGER", 0) != 0;           // tuning / A-B knobs (undocumented defaults are the product path)
+    rl.thresh_a = env_int("GDPT_THRESH_A", 0); rl.thresh_c = env_int("GDPT_THRESH_C", 0);
+    rl.force_log2k = env_int("GDPT_LOG2K", -1);
+    rl.waves_per_simd = env_int("GDPT_WPS", 2);
+    if (env_int("GDPT_NO_LDS_SCENE", 0)) rl.scene_fits_lds = false;
     ck(hipMemsetAsync(sc->d_counters, 0, sizeof(gdpt::RenderCounters), stream), "hipMemsetAsync(counters)");
     if (stats) ck(hipEventRecord(sc->ev0, stream), "hipEventRecord");
     gdpt::launch_render(sc->view, rl, stream);

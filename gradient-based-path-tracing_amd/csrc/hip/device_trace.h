@@ -78,13 +78,7 @@ GD void test_prim(const DevSceneView &sv, const DevPrim &pr, const float o[3], c
         float t, u, v;
         if (!tri_hit(o, d, tnear, tfar, pr, t, u, v)) return;
         if (best.gid >= 0 && !(t < best.t || (t == best.t && (int)gid < best.gid))) return;
-        best.t = t; best.u = u; best.v = v; best.gid = (int)gid;
-        {
-#pragma clang fp contract(off)
-            best.ngx = pr.e1[1] * pr.e2[2] - pr.e1[2] * pr.e2[1];
-            best.ngy = pr.e1[2] * pr.e2[0] - pr.e1[0] * pr.e2[2];
-            best.ngz = pr.e1[0] * pr.e2[1] - pr.e1[1] * pr.e2[0];
-        }
+        best.t = t; best.u = u; best.v = v; best.gid = (int)gid;   // Ng: per-triangle constant, see DevTriShade::gn
     } else {
         Hit h;
         if (!sphere_hit(o, d, tnear, tfar, sv.spheres[gid & ~GDPT_SPHERE_FLAG], h)) return;
@@ -154,24 +148,15 @@ GD Hit closest_hit(const DevSceneView &sv, const float o[3], const float d[3], f
 // ---- intersect() post-processing: src/intersection.cpp:37-63 + compute_shading_info ----------------
 struct Ray { D3 org, dir; double tnear, tfar; };
 
-GD void shading_info_tri(const DevTriShade &ts, D2 st, D3 gn, D2 &uv, Frame &frame, double &inv_uv_size) {
-    // src/shapes/triangle_mesh.inl:77-169 (mean curvature is never read on the GradPath path: skipped)
+GD void shading_info_tri(const DevTriShade &ts, D2 st, D3 gn, bool need_uv, D2 &uv, Frame &frame, double &inv_uv_size) {
+    // src/shapes/triangle_mesh.inl:77-169. dp/du, dp/dv and max(|dpdu|,|dpdv|) do not depend on the hit point and
+    // come precomputed (host, same formulas); mean curvature is never read on the GradPath path: skipped.
     double b0 = 1 - st.x - st.y;
-    uv.x = b0 * ts.uv[0][0] + st.x * ts.uv[1][0] + st.y * ts.uv[2][0];
-    uv.y = b0 * ts.uv[0][1] + st.x * ts.uv[1][1] + st.y * ts.uv[2][1];
-    D3 p0 = mk(ts.p[0][0], ts.p[0][1], ts.p[0][2]), p1 = mk(ts.p[1][0], ts.p[1][1], ts.p[1][2]), p2 = mk(ts.p[2][0], ts.p[2][1], ts.p[2][2]);
-    double dsx = ts.uv[2][0] - ts.uv[0][0], dsy = ts.uv[2][1] - ts.uv[0][1];   // duvds
-    double dtx = ts.uv[2][0] - ts.uv[1][0], dty = ts.uv[2][1] - ts.uv[1][1];   // duvdt
-    double det = dsx * dty - dtx * dsy;
-    D3 dpdu, dpdv;
-    if (fabs(det) > (double)1e-8f) {
-        double dsdu = dty / det, dtdu = -dsy / det, dsdv = dtx / det, dtdv = -dsx / det;
-        D3 dpds = p2 - p0, dpdt = p2 - p1;
-        dpdu = dpds * dsdu + dpdt * dtdu;
-        dpdv = dpds * dsdv + dpdt * dtdv;
-    } else {
-        coordinate_system(gn, dpdu, dpdv);
-    }
+    if (need_uv) {
+        uv.x = b0 * ts.uv[0][0] + st.x * ts.uv[1][0] + st.y * ts.uv[2][0];
+        uv.y = b0 * ts.uv[0][1] + st.x * ts.uv[1][1] + st.y * ts.uv[2][1];
+    } else { uv.x = uv.y = 0; }
+    D3 dpdu = mk(ts.dpdu[0], ts.dpdu[1], ts.dpdu[2]);
     D3 sn = gn;
     if (ts.has_normals) {
         D3 n0 = mk(ts.n[0][0], ts.n[0][1], ts.n[0][2]), n1 = mk(ts.n[1][0], ts.n[1][1], ts.n[1][2]), n2 = mk(ts.n[2][0], ts.n[2][1], ts.n[2][2]);
@@ -180,7 +165,7 @@ GD void shading_info_tri(const DevTriShade &ts, D2 st, D3 gn, D2 &uv, Frame &fra
     D3 tangent = normalize(dpdu - sn * dot(sn, dpdu));
     D3 bitangent = normalize(cross(sn, tangent));
     frame.x = tangent; frame.y = bitangent; frame.n = sn;
-    inv_uv_size = fmax(length(dpdu), length(dpdv));
+    inv_uv_size = ts.inv_uv_size;
 }
 
 GD void shading_info_sphere(const DevSphere &sp, D2 st, D3 gn, D2 &uv, Frame &frame, double &inv_uv_size) {
@@ -198,37 +183,34 @@ GD void shading_info_sphere(const DevSphere &sp, D2 st, D3 gn, D2 &uv, Frame &fr
 }
 
 // Builds the PathVertex of a hit. rd_spread/rd_radius: RayDifferential of the query (src/ray.h:26-40).
-GD void make_vertex(const DevSceneView &sv, const Ray &ray, const Hit &h, double rd_radius, double rd_spread, Vertex &v) {
+// `tris` is the shading table (HBM, or the block's LDS copy); `need_uv`: some texture is not constant.
+GD void make_vertex(const DevSceneView &sv, const DevTriShade *tris, bool need_uv, const Ray &ray, const Hit &h,
+                    double rd_radius, double rd_spread, Vertex &v) {
     v.position = ray.org + ray.dir * (double)h.t;
-    D3 gn = normalize(mk((double)h.ngx, (double)h.ngy, (double)h.ngz));
     D2 st; st.x = (double)h.u; st.y = (double)h.v;
     double inv_uv_size;
+    D3 gn;
     if (h.gid < sv.num_tris) {
-        const DevTriShade &ts = sv.tris[h.gid];
+        const DevTriShade &ts = tris[h.gid];
         v.material_id = ts.material_id; v.light_id = ts.light_id;
-        shading_info_tri(ts, st, gn, v.uv, v.frame, inv_uv_size);
+        gn = mk(ts.gn[0], ts.gn[1], ts.gn[2]);
+        shading_info_tri(ts, st, gn, need_uv, v.uv, v.frame, inv_uv_size);
     } else {
         const DevSphere &sp = sv.spheres[h.gid - sv.num_tris];
         v.material_id = sp.material_id; v.light_id = sp.light_id;
+        gn = normalize(mk((double)h.ngx, (double)h.ngy, (double)h.ngz));
         shading_info_sphere(sp, st, gn, v.uv, v.frame, inv_uv_size);
     }
-    D3 dlt = ray.org - v.position;
-    double dist = sqrt(dot(dlt, dlt));
-    double ray_radius = rd_radius + rd_spread * dist;
-    v.uv_screen_size = ray_radius / inv_uv_size;
+    if (need_uv && rd_spread != 0.0) {
+        D3 dlt = ray.org - v.position;
+        double dist = sqrt(dot(dlt, dlt));
+        double ray_radius = rd_radius + rd_spread * dist;
+        v.uv_screen_size = ray_radius / inv_uv_size;
+    } else {
+        v.uv_screen_size = 0.0;     // secondary rays carry the default RayDifferential{0,0} (src/path_tracing.h:564)
+    }
     if (dot(gn, v.frame.n) < 0) gn = -gn;
     v.gn = gn;
-}
-
-template <bool COUNT>
-GD bool intersect(const DevSceneView &sv, const Ray &ray, double rd_radius, double rd_spread, Vertex &v,
-                  int *stack, int stride, TraceCounters &tc) {
-    float o[3] = {(float)ray.org.x, (float)ray.org.y, (float)ray.org.z};
-    float d[3] = {(float)ray.dir.x, (float)ray.dir.y, (float)ray.dir.z};
-    Hit h = closest_hit<COUNT>(sv, o, d, (float)ray.tnear, (float)ray.tfar, stack, stride, tc);
-    if (h.gid < 0) return false;
-    make_vertex(sv, ray, h, rd_radius, rd_spread, v);
-    return true;
 }
 
 // emission(), src/intersection.cpp:87-98 + src/lights/diffuse_area_light.inl:15-20

@@ -1,0 +1,705 @@
+// render_device.h — the GDPT sample evaluator and tile loop for gfx950.
+//
+// Restates gradient_path_render's tile loop (src/render.cpp:277-331) and grad_path_tracing
+// (src/path_tracing.h:354-1050): one base path plus four pixel-offset paths per sample, BSDF sampling
+// only (no NEE/MIS on this integrator), Russian roulette from rr_depth, per-pixel accumulation of
+// img, cx0, cy0, cx1, cy1. The four undefined end-of-bounce reads (src/path_tracing.h:1007-1010) use
+// the "A-semantics" of SURVEY.md §8(a) G2: an offset keeps its primary hit for the whole path.
+//
+// Two evaluators live here:
+//
+//  * phase machine (scenes whose materials are all one-sided lobes: Lambertian, DisneyDiffuse/Metal/
+//    Clearcoat/Sheen — cbox, sponza). A sample is cut into three phases:
+//        A  base primary ray + the first bounce iteration (2 rays)
+//        B  one later bounce iteration (1 ray)
+//        C  the four offset paths (4 rays) + accumulation of the sample's record
+//    Offsets never feed back into the base path or the RNG stream (they reuse the base's numbers), and for
+//    one-sided lobes an offset that survives bounce 1 is retired by bounce 2 (its next sample_bsdf sees
+//    dir_in below the surface, or the material test fails). So an offset is observable only when the base
+//    path leaves the loop during bounce 1, or at the p2<=0 exit of bounce 2, and phase C runs only then —
+//    with bounce-1 random numbers re-derived from the sample's PCG stream. Each lane owns (pixel, chunk of
+//    samples); a wave runs a phase when enough lanes wait for it (ballot counts), so lanes whose path has
+//    ended pick up their next sample instead of idling behind the longest path of the wave.
+//    Exactness: identical to the eager evaluation except when dot(geometric_normal, dir) of a surviving
+//    offset is exactly 0 while its pdf is > 0 (then the reference would carry it one more bounce).
+//
+//  * eager evaluator (any scene; used when a two-sided lobe — DisneyGlass, DisneyBSDF — is present, and by
+//    the checks): the straight loop with offset state carried in private memory.
+//
+// Traversal is fp32 with a per-lane stack in LDS (and, for small scenes, BVH nodes + primitive records
+// resident in LDS); shading is fp64 with per-lane PCG32 state in registers. K lanes per pixel sit next to each
+// other in a wave and are combined with a fixed-order xor-shuffle tree: one writer per pixel, no atomics,
+// run-to-run deterministic.
+#pragma once
+#include "render_kernels.h"
+#include "device_trace.h"
+
+namespace gd {
+
+constexpr int kBlock = 256;
+constexpr int kLdsSceneBytes = 24 * 1024;     // nodes + prims + shading table + materials of a "small" scene
+constexpr int kLdsSceneLevels = 16;           // stack slots per lane when the scene is LDS-resident
+
+struct LaneCounters { unsigned rays, bounces, nonfinite; };
+struct Accum { D3 r, dx0, dy0, dx1, dy1; };
+
+struct KernelArgs {
+    int spp, log2k, tile_w, tile_h, tiles_x;
+    int row_begin, row_end, max_depth;
+    int thresh_a, thresh_c;
+    int count, pad_;
+    double *img, *cx0, *cy0, *cx1, *cy1;
+    gdpt::RenderCounters *counters;
+};
+
+GD bool loop_allows(int max_depth, int num_vertices) { return max_depth == -1 || num_vertices <= max_depth + 1; }   // :515
+
+// ------------------------------------------------------------------------------------------------
+// accumulation of one GraidentPTRadiance into the pixel sums (src/render.cpp:311-318)
+// ------------------------------------------------------------------------------------------------
+// Two homes for a lane's 15 running sums: registers (serial kernels) or the block's LDS, one private slot per lane
+// and component, updated with return-less ds_add_f64 (frees 30 VGPRs; one writer per slot, so still deterministic).
+struct AccReg {
+    Accum a;
+    GD void init() { a.r = a.dx0 = a.dy0 = a.dx1 = a.dy1 = splat(0); }
+    GD void add(int which, D3 v) {     // which: 0 r, 1 dx0, 2 dy0, 3 dx1, 4 dy1
+        if (which == 0) a.r = a.r + v; else if (which == 1) a.dx0 = a.dx0 + v; else if (which == 2) a.dy0 = a.dy0 + v;
+        else if (which == 3) a.dx1 = a.dx1 + v; else a.dy1 = a.dy1 + v;
+    }
+    GD Accum result() { return a; }
+};
+struct AccLds {
+    double *slot;   // &s_acc[0][tid]; component c lives at slot[c * stride]
+    int stride;
+    GD void init() { for (int c = 0; c < 15; c++) slot[c * stride] = 0.0; }
+    GD void add(int which, D3 v) {
+        double *p = slot + which * 3 * stride;
+        __hip_atomic_fetch_add(p, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p + stride, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p + 2 * stride, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    GD Accum result() {
+        Accum a;
+        a.r = mk(slot[0], slot[stride], slot[2 * stride]);
+        a.dx0 = mk(slot[3 * stride], slot[4 * stride], slot[5 * stride]);
+        a.dy0 = mk(slot[6 * stride], slot[7 * stride], slot[8 * stride]);
+        a.dx1 = mk(slot[9 * stride], slot[10 * stride], slot[11 * stride]);
+        a.dy1 = mk(slot[12 * stride], slot[13 * stride], slot[14 * stride]);
+        return a;
+    }
+};
+
+template <class ACC>
+GD void acc_base(ACC &a, D3 radiance, double prob, double spp, LaneCounters &lc) {
+    if (!(isfinite(prob) && isfinite(radiance.x + radiance.y + radiance.z))) lc.nonfinite++;
+    if (prob > 0.0) a.add(0, radiance / spp);
+}
+// k: 0 = x0, 1 = x1, 2 = y0, 3 = y1
+template <class ACC>
+GD void acc_offset(ACC &a, int k, D3 contrib, D3 cX, double w, double prob, double spp, LaneCounters &lc, bool &flagged) {
+    if (!(isfinite(cX.x + cX.y + cX.z) && isfinite(w) && isfinite(contrib.x + contrib.y + contrib.z))) { if (!flagged) lc.nonfinite++; flagged = true; }
+    if (!(prob > 0.0)) return;
+    double f = w / (prob * spp);
+    if (k == 0) a.add(1, (contrib - cX) * f);
+    else if (k == 1) a.add(3, (cX - contrib) * f);
+    else if (k == 2) a.add(2, (contrib - cX) * f);
+    else a.add(4, (cX - contrib) * f);
+}
+// a finished sample whose four offsets are all dead: contribX = 0, wX = 1 (struct defaults, src/intersection.h:65-77)
+template <class ACC>
+GD void acc_no_offsets(ACC &a, D3 radiance, D3 contrib, double prob, double spp, LaneCounters &lc) {
+    bool finite = isfinite(prob) && isfinite(radiance.x + radiance.y + radiance.z) && isfinite(contrib.x + contrib.y + contrib.z);
+    if (!finite) lc.nonfinite++;
+    if (prob > 0.0) {
+        a.add(0, radiance / spp);
+        D3 t = contrib * (1.0 / (prob * spp));
+        a.add(1, t); a.add(2, t);
+        a.add(3, -t); a.add(4, -t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scene memory view: BVH nodes / primitive records from HBM or from the block's LDS copy
+// ------------------------------------------------------------------------------------------------
+struct TraceCtx {
+    const DevBvhNode *nodes;
+    const DevPrim *prims;
+    const DevTriShade *tris;
+    const GdptMaterial *materials;
+    int *stack;
+    int stride;
+    bool count;       // wave-uniform: count BVH nodes / primitives (bench roofline accounting)
+    bool need_uv;     // wave-uniform: some texture is not constant (uv / footprint are observable)
+};
+
+GD Hit closest_hit_ctx(const DevSceneView &sv, const TraceCtx &tx, const float o[3], const float d[3], float tnear, float tfar, TraceCounters &tc) {
+    Hit best; best.gid = -1; best.t = tfar; best.u = best.v = 0; best.ngx = best.ngy = best.ngz = 0;
+    if (sv.num_nodes == 0) return best;
+    float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+    int sp = 0, cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const DevBvhNode &n = tx.nodes[cur];
+            if (tx.count) tc.nodes++;
+            float tb = best.t, tl, tr;
+            bool hl = (n.left != GDPT_CHILD_EMPTY) && box_hit(n.lmin, n.lmax, o, inv, tnear, tb, tl);
+            bool hr = (n.right != GDPT_CHILD_EMPTY) && box_hit(n.rmin, n.rmax, o, inv, tnear, tb, tr);
+            if (hl && hr) {
+                int nearc = n.left, farc = n.right;
+                if (tr < tl) { nearc = n.right; farc = n.left; }
+                tx.stack[sp * tx.stride] = farc; sp++;
+                cur = nearc;
+                continue;
+            } else if (hl) { cur = n.left; continue; }
+            else if (hr) { cur = n.right; continue; }
+        } else {
+            unsigned packed = ~(unsigned)cur;
+            unsigned first = packed >> 2, cnt = (packed & 3u) + 1u;
+            for (unsigned i = 0; i < cnt; i++) {
+                if (tx.count) tc.prims++;
+                test_prim(sv, tx.prims[first + i], o, d, tnear, tfar, best);
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = tx.stack[sp * tx.stride];
+    }
+    return best;
+}
+
+GD bool intersect_ctx(const DevSceneView &sv, const TraceCtx &tx, const Ray &ray, double rd_spread, Vertex &v, LaneCounters &lc, TraceCounters &tc) {
+    float o[3] = {(float)ray.org.x, (float)ray.org.y, (float)ray.org.z};
+    float d[3] = {(float)ray.dir.x, (float)ray.dir.y, (float)ray.dir.z};
+    lc.rays++;
+    Hit h = closest_hit_ctx(sv, tx, o, d, (float)ray.tnear, (float)ray.tfar, tc);
+    if (h.gid < 0) return false;
+    make_vertex(sv, tx.tris, tx.need_uv, ray, h, 0.0, rd_spread, v);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// material dispatch: Lambertian-only scenes get the three-line lobe inline, others the full switch
+// ------------------------------------------------------------------------------------------------
+template <bool LAMBERT>
+GD bool mat_sample(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D2 ruv, double rw, BsdfSample &s) {
+    if (LAMBERT) { Ctx c{sv, v}; return cos_sample(c, in, ruv, 1.0, s); }
+    return bsdf_sample(sv, tx.materials[v.material_id], in, v, ruv, rw, s);
+}
+// eval (f*|cos|) and solid-angle pdf together
+template <bool LAMBERT>
+GD void mat_eval_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D3 out, D3 &f, double &pdf) {
+    if (LAMBERT) {
+        // src/materials/lambertian.inl:1-33 — eval and pdf share the clamped cosine
+        if (below(v, in) || below(v, out)) { f = splat(0); pdf = 0; return; }
+        Frame fr = oriented_frame(v, in);
+        double c = fmax(dot(fr.n, out), 0.0);
+        f = c * tex3(sv, tx.materials[v.material_id].tex[0], v) / kPi;
+        pdf = c / kPi;
+        return;
+    }
+    const GdptMaterial &m = tx.materials[v.material_id];
+    f = bsdf_eval(sv, m, in, out, v);
+    pdf = bsdf_pdf(sv, m, in, out, v);
+}
+template <bool LAMBERT>
+GD double mat_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D3 out) {
+    if (LAMBERT) { Ctx c{sv, v}; return cos_pdf(c, in, out); }
+    return bsdf_pdf(sv, tx.materials[v.material_id], in, out, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// one-ray-per-iteration lane machine
+// ------------------------------------------------------------------------------------------------
+// A lane always holds ONE pending ray. Every loop iteration each live lane traces its pending ray and rebuilds the
+// hit vertex — the bulk of the instructions, executed with all lanes active — then a short state-dependent part
+// consumes the hit and prepares the lane's next pending ray:
+//   S_PRIMARY  base camera ray of the lane's current sample
+//   S_BOUNCE   bounce ray of the base path; f and the solid-angle pdf of its direction were evaluated at the
+//              vertex it leaves, so no vertex has to stay in registers across the traversal
+//   S_OFFSET   camera ray of offset k of a base path that stopped where offsets are observable (lazy, see header)
+enum { S_START = 0, S_PRIMARY = 1, S_BOUNCE = 2, S_OFFSET = 3, S_DONE = 4 };
+enum { ACT_NONE = 0, ACT_BOUNCE = 1, ACT_OFFSETS = 2, ACT_NEXT_SAMPLE = 3, ACT_PRIMARY_RAY = 4, ACT_OFFSET_RAY = 5 };
+// why the base path stopped, which decides what the offsets still do
+enum { C_NO_LOOP = 0,        // the bounce loop never ran (max_depth < 2): jacobian 1
+       C_AFTER_BOUNCE1 = 1,  // left the loop in bounce 1 after the updates: offsets were re-sampled in bounce 1
+       C_BROKE_BOUNCE1 = 2,  // p2 <= 0 in bounce 1 (break before the offsets' re-sampling): jacobian 1
+       C_BROKE_BOUNCE2 = 3 };// p2 <= 0 in bounce 2: bounce-1 jacobian (bounce 2's material test already passed)
+
+struct Lane {
+    int st, k, s, s_end;
+    int mat0, mat1, cmode, num_vertices;
+    Pcg rng;
+    D3 org, dir;              // the pending ray
+    D3 f; double pdf;         // S_BOUNCE: f*|cos| and solid-angle pdf of `dir` at the vertex the ray leaves
+    D3 contrib, throughput, radiance;
+    double prob, eta_scale;
+    double p2_1;              // base p2 (incl. G) of bounce 1
+    double rng_x, rng_y;      // serial-RNG (TILE) mode only: the sample's sub-pixel and bounce-1 numbers
+    D2 ruv1; double rw1;      // (SAMPLE mode re-derives them from the sample's own PCG stream)
+};
+
+// SERIAL_RNG: one PCG stream runs through consecutive samples (TILE scheme); otherwise each sample owns stream
+// `base + s` (SAMPLE scheme) and its sub-pixel / bounce-1 numbers are re-derived from it when an offset needs them.
+template <bool LAMBERT, bool SERIAL_RNG, class ACC>
+GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, double spp, int x, int y, unsigned long long base,
+                  Lane &L, ACC &acc, LaneCounters &lc, TraceCounters &tc) {
+    const DevCamera &cam = sv.cam;
+    const int w = cam.width, h = cam.height;
+    const int st0 = L.st;
+    int act = ACT_NONE;
+    Vertex nv;
+    Ray ray;
+    ray.org = L.org; ray.dir = L.dir; ray.tfar = __builtin_huge_val();
+    ray.tnear = (st0 == S_BOUNCE) ? sv.isect_eps : 0.0;
+    // ---------------- TRACE (uniform over the wave) ----------------
+    const bool tracing = (st0 == S_PRIMARY || st0 == S_BOUNCE || st0 == S_OFFSET);
+    bool hit = false;
+    if (tracing) hit = intersect_ctx(sv, tx, ray, (st0 == S_BOUNCE) ? 0.0 : 0.25 / (double)max(w, h), nv, lc, tc);   // src/ray.h:33-35, :564
+    // ---------------- consume the hit ----------------
+    if (st0 == S_START) {
+        act = ACT_PRIMARY_RAY;
+    } else if (st0 == S_PRIMARY) {
+        if (!hit) act = ACT_NEXT_SAMPLE;                                            // :375-379: zero record, adds nothing
+        else {
+            L.mat0 = nv.material_id; L.mat1 = -1;
+            L.contrib = splat(1.0); L.throughput = splat(1.0); L.radiance = splat(0);
+            L.prob = 1.0; L.eta_scale = 1.0; L.p2_1 = 1.0;
+            if (nv.light_id >= 0) { D3 Le = emission(sv, nv, -ray.dir); L.radiance = Le; L.contrib = Le; }   // :490-493
+            L.num_vertices = 3;
+            if (!loop_allows(max_depth, 3)) { L.cmode = C_NO_LOOP; act = ACT_OFFSETS; } else act = ACT_BOUNCE;
+        }
+    } else if (st0 == S_BOUNCE) {
+        const bool first = (L.num_vertices == 3);
+        double G = 1.0;
+        if (hit) { D3 dl = nv.position - ray.org; G = fabs(dot(ray.dir, nv.gn)) / dot(dl, dl); }   // :746-753
+        const D3 f = L.f;
+        double p2 = L.pdf * G;                                                      // :766
+        L.contrib = L.contrib * f * G; L.prob *= p2;                                // :769-770
+        if (first) L.p2_1 = p2;
+        if (hit && nv.light_id >= 0) {                                              // :971-980
+            D3 Le = emission(sv, nv, -ray.dir);
+            D3 C2 = (G * f) * Le;
+            L.contrib = L.contrib * Le;
+            L.radiance = L.radiance + L.throughput * (C2 / p2);
+        }
+        bool stop = !hit;                                                           // :982-985
+        if (!stop) {
+            double rr_prob = 1;
+            if (L.num_vertices - 1 >= sv.rr_depth) {                                // :992-999
+                rr_prob = fmin(maxc((1 / L.eta_scale) * L.throughput), 0.95);
+                if (pcg_real(L.rng) > rr_prob) stop = true;
+            }
+            if (!stop) {
+                L.throughput = L.throughput * (G * f) / (p2 * rr_prob);             // :1003
+                L.num_vertices++;
+                if (first) L.mat1 = nv.material_id;
+                if (!loop_allows(max_depth, L.num_vertices)) stop = true;
+            }
+        }
+        if (!stop) act = ACT_BOUNCE;
+        else if (first) { L.cmode = C_AFTER_BOUNCE1; act = ACT_OFFSETS; }
+        else { acc_no_offsets(acc, L.radiance, L.contrib, L.prob, spp, lc); act = ACT_NEXT_SAMPLE; }
+        // (one-sided lobes: offsets alive after bounce 1 are retired by bounce 2's re-sampling, see file header)
+    } else if (st0 == S_OFFSET) {
+        const int k = L.k;
+        D3 cX = splat(0);
+        double wgt = 1.0;
+        if (hit && nv.material_id == L.mat0) {                                      // :424-443
+            D3 c0 = (nv.light_id >= 0) ? emission(sv, nv, -ray.dir) : splat(1.0);   // :496-508
+            double jac = 1.0;
+            bool alive = true;
+            if (L.cmode == C_AFTER_BOUNCE1 || L.cmode == C_BROKE_BOUNCE2) {         // :773-959: re-sampled with the base's numbers
+                D2 ruv1; double rw1;
+                if (SERIAL_RNG) { ruv1 = L.ruv1; rw1 = L.rw1; }
+                else {
+                    Pcg r2 = pcg_init(base + (unsigned long long)L.s);
+                    (void)pcg_next(r2); (void)pcg_next(r2);
+                    ruv1.x = pcg_real(r2); ruv1.y = pcg_real(r2); rw1 = pcg_real(r2);
+                }
+                D3 oin = -ray.dir;
+                BsdfSample os;
+                if (!mat_sample<LAMBERT>(sv, tx, nv, oin, ruv1, rw1, os)) alive = false;
+                else {
+                    double p2o = mat_pdf<LAMBERT>(sv, tx, nv, oin, os.dir_out);
+                    if (p2o <= 0.0) alive = false; else jac = L.p2_1 / p2o;        // :813
+                }
+            }
+            if (alive) { cX = c0 * jac; wgt = L.prob / (L.prob + 1.0 * jac); }      // :1019-1045
+        }
+        bool flagged = false;
+        acc_offset(acc, k, L.contrib, cX, wgt, L.prob, spp, lc, flagged);
+        if (k == 3) { acc_base(acc, L.radiance, L.prob, spp, lc); act = ACT_NEXT_SAMPLE; }
+        else { L.k = k + 1; act = ACT_OFFSET_RAY; }
+    }
+    // ---------------- prepare the lane's next pending ray ----------------
+    if (act == ACT_BOUNCE) {                                                         // bounce iteration L.num_vertices starts at `nv`
+        lc.bounces++;
+        D2 ruv; ruv.x = pcg_real(L.rng); ruv.y = pcg_real(L.rng);                   // :536-537
+        double rw = pcg_real(L.rng);
+        if (SERIAL_RNG && L.num_vertices == 3) { L.ruv1 = ruv; L.rw1 = rw; }
+        const D3 dir_view = -ray.dir;
+        BsdfSample bs;
+        if (!mat_sample<LAMBERT>(sv, tx, nv, dir_view, ruv, rw, bs)) act = ACT_NEXT_SAMPLE;   // :545-548: GraidentPTRadiance{}
+        else {
+            if (bs.eta != 0) L.eta_scale /= (bs.eta * bs.eta);                      // :553-558
+            D3 f; double pdf;
+            mat_eval_pdf<LAMBERT>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
+            if (pdf <= 0) {                                                         // :760-763: break before any update; the ray's
+                if (L.num_vertices == 3) { L.cmode = C_BROKE_BOUNCE1; act = ACT_OFFSETS; }           // hit is unobservable
+                else if (L.num_vertices == 4 && L.mat0 == L.mat1) { L.cmode = C_BROKE_BOUNCE2; act = ACT_OFFSETS; }   // :607-612 passed
+                else { acc_no_offsets(acc, L.radiance, L.contrib, L.prob, spp, lc); act = ACT_NEXT_SAMPLE; }
+            } else {
+                L.org = nv.position; L.dir = bs.dir_out; L.f = f; L.pdf = pdf; L.st = S_BOUNCE;
+            }
+        }
+    }
+    if (act == ACT_OFFSETS) { L.k = 0; act = ACT_OFFSET_RAY; }
+    if (act == ACT_NEXT_SAMPLE) {
+        L.s++;
+        if (L.s >= L.s_end) L.st = S_DONE; else act = ACT_PRIMARY_RAY;
+    }
+    if (act == ACT_PRIMARY_RAY || act == ACT_OFFSET_RAY) {
+        double rx, ry;
+        int ox = 0, oy = 0;
+        if (act == ACT_PRIMARY_RAY) {
+            if (!SERIAL_RNG) L.rng = pcg_init(base + (unsigned long long)L.s);
+            rx = pcg_real(L.rng); ry = pcg_real(L.rng);                             // :360-361
+            if (SERIAL_RNG) { L.rng_x = rx; L.rng_y = ry; }
+            L.st = S_PRIMARY;
+        } else {
+            if (SERIAL_RNG) { rx = L.rng_x; ry = L.rng_y; }
+            else { Pcg r2 = pcg_init(base + (unsigned long long)L.s); rx = pcg_real(r2); ry = pcg_real(r2); }
+            const int k = L.k;
+            ox = (k == 0) ? -1 : (k == 1 ? 1 : 0); oy = (k == 2) ? 1 : (k == 3 ? -1 : 0);   // x0,x1,y0,y1 (:385-403)
+            L.st = S_OFFSET;
+        }
+        Ray r = sample_primary(cam, ((x + ox) + rx) / w, ((y + oy) + ry) / h);
+        L.org = r.org; L.dir = r.dir;
+    }
+}
+
+GD unsigned wave_sum_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+GD unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+GD void flush_counters(const KernelArgs &a, const LaneCounters &lc, const TraceCounters &tc, bool count) {
+    unsigned r = wave_sum_u32(lc.rays), b = wave_sum_u32(lc.bounces), nf = wave_sum_u32(lc.nonfinite);
+    unsigned long long nn = 0, np = 0;
+    if (count) { nn = wave_sum_u64(tc.nodes); np = wave_sum_u64(tc.prims); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&a.counters->rays, (unsigned long long)r);
+        atomicAdd(&a.counters->bounces, (unsigned long long)b);
+        if (nf) atomicAdd(&a.counters->nonfinite, (unsigned long long)nf);
+        if (count) { atomicAdd(&a.counters->nodes, nn); atomicAdd(&a.counters->prims, np); }
+    }
+}
+
+GD void reduce_and_store(const KernelArgs &a, Accum &acc, int K, bool writer, int x, int y, int W) {
+    // fixed-order tree over the K lanes of a pixel (lanes of one pixel are contiguous and K-aligned)
+    for (int o = K >> 1; o >= 1; o >>= 1) {
+        acc.r.x += __shfl_xor(acc.r.x, o, 64); acc.r.y += __shfl_xor(acc.r.y, o, 64); acc.r.z += __shfl_xor(acc.r.z, o, 64);
+        acc.dx0.x += __shfl_xor(acc.dx0.x, o, 64); acc.dx0.y += __shfl_xor(acc.dx0.y, o, 64); acc.dx0.z += __shfl_xor(acc.dx0.z, o, 64);
+        acc.dy0.x += __shfl_xor(acc.dy0.x, o, 64); acc.dy0.y += __shfl_xor(acc.dy0.y, o, 64); acc.dy0.z += __shfl_xor(acc.dy0.z, o, 64);
+        acc.dx1.x += __shfl_xor(acc.dx1.x, o, 64); acc.dx1.y += __shfl_xor(acc.dx1.y, o, 64); acc.dx1.z += __shfl_xor(acc.dx1.z, o, 64);
+        acc.dy1.x += __shfl_xor(acc.dy1.x, o, 64); acc.dy1.y += __shfl_xor(acc.dy1.y, o, 64); acc.dy1.z += __shfl_xor(acc.dy1.z, o, 64);
+    }
+    if (writer) {
+        size_t i = ((size_t)y * W + x) * 3;
+        a.img[i] = acc.r.x; a.img[i + 1] = acc.r.y; a.img[i + 2] = acc.r.z;
+        a.cx0[i] = acc.dx0.x; a.cx0[i + 1] = acc.dx0.y; a.cx0[i + 2] = acc.dx0.z;
+        a.cy0[i] = acc.dy0.x; a.cy0[i + 1] = acc.dy0.y; a.cy0[i + 2] = acc.dy0.z;
+        a.cx1[i] = acc.dx1.x; a.cx1[i + 1] = acc.dx1.y; a.cx1[i + 2] = acc.dx1.z;
+        a.cy1[i] = acc.dy1.x; a.cy1[i + 1] = acc.dy1.y; a.cy1[i + 2] = acc.dy1.z;
+    }
+}
+
+GD int lds_scene_bytes(const DevSceneView &sv) {
+    return sv.num_nodes * (int)sizeof(DevBvhNode) + sv.num_prims * (int)sizeof(DevPrim) + sv.num_tris * (int)sizeof(DevTriShade) +
+           sv.num_materials * (int)sizeof(GdptMaterial);
+}
+// Copies nodes, primitive records, the shading table and the materials into LDS (small scenes) and returns the
+// trace context of this lane.
+template <bool LDS_SCENE>
+GD TraceCtx setup_trace(const DevSceneView &sv, unsigned char *s_scene, int *s_stack, int tid, int nthreads, bool count) {
+    TraceCtx tx;
+    tx.count = count;
+    tx.need_uv = !sv.all_textures_constant;
+    tx.stack = s_stack + tid; tx.stride = nthreads;
+    if (LDS_SCENE) {
+        const int nw = sv.num_nodes * (int)(sizeof(DevBvhNode) / 4), pw = sv.num_prims * (int)(sizeof(DevPrim) / 4);
+        const int tw = sv.num_tris * (int)(sizeof(DevTriShade) / 4), mw = sv.num_materials * (int)(sizeof(GdptMaterial) / 4);
+        unsigned *dst = (unsigned *)s_scene;
+        const unsigned *s0 = (const unsigned *)sv.nodes, *s1 = (const unsigned *)sv.prims, *s2 = (const unsigned *)sv.tris, *s3 = (const unsigned *)sv.materials;
+        for (int i = tid; i < nw; i += nthreads) dst[i] = s0[i];
+        for (int i = tid; i < pw; i += nthreads) dst[nw + i] = s1[i];
+        for (int i = tid; i < tw; i += nthreads) dst[nw + pw + i] = s2[i];
+        for (int i = tid; i < mw; i += nthreads) dst[nw + pw + tw + i] = s3[i];
+        __syncthreads();
+        tx.nodes = (const DevBvhNode *)s_scene;
+        tx.prims = (const DevPrim *)(s_scene + (size_t)nw * 4);
+        tx.tris = (const DevTriShade *)(s_scene + (size_t)(nw + pw) * 4);
+        tx.materials = (const GdptMaterial *)(s_scene + (size_t)(nw + pw + tw) * 4);
+    } else {
+        tx.nodes = sv.nodes; tx.prims = sv.prims; tx.tris = sv.tris; tx.materials = sv.materials;
+    }
+    return tx;
+}
+
+// SAMPLE stream: init_pcg32((y*W+x)*spp + s) per sample; K = 2^log2k lanes share a pixel, each owns a chunk of
+// its samples. WPS = waves per SIMD the register allocator must leave room for.
+template <bool LAMBERT, bool LDS_SCENE, int WPS>
+__global__ __launch_bounds__(kBlock, WPS) void gdpt_render_phases(DevSceneView sv, KernelArgs a) {
+    constexpr int kLevels = LDS_SCENE ? kLdsSceneLevels : GDPT_BVH_MAX_DEPTH;
+    __shared__ int s_stack[kLevels * kBlock];
+    __shared__ __attribute__((aligned(16))) unsigned char s_scene[LDS_SCENE ? kLdsSceneBytes : 16];
+    const int tid = threadIdx.x;
+    TraceCtx tx = setup_trace<LDS_SCENE>(sv, s_scene, s_stack, tid, kBlock, a.count != 0);
+    const int K = 1 << a.log2k;
+    const int c = tid & (K - 1), p = tid >> a.log2k;
+    const int px = p % a.tile_w, py = p / a.tile_w;
+    const int bx = blockIdx.x % a.tiles_x, by = blockIdx.x / a.tiles_x;
+    const int x = bx * a.tile_w + px, y = a.row_begin + by * a.tile_h + py;
+    const int W = sv.cam.width;
+    const bool valid = (x < W) && (y < a.row_end);
+    const double spp = (double)a.spp;
+    __shared__ double s_acc[15 * kBlock];
+    AccLds acc; acc.slot = s_acc + tid; acc.stride = kBlock;
+    acc.init();
+    LaneCounters lc = {0, 0, 0};
+    TraceCounters tc = {0, 0};
+    const unsigned long long base = ((unsigned long long)(valid ? y : 0) * W + (valid ? x : 0)) * (unsigned long long)a.spp;
+    Lane L;
+    L.s = (int)(((long long)c * a.spp) >> a.log2k);
+    L.s_end = (int)(((long long)(c + 1) * a.spp) >> a.log2k);
+    L.st = (valid && L.s < L.s_end) ? S_START : S_DONE;
+    L.k = 0; L.num_vertices = 0; L.cmode = 0; L.mat0 = L.mat1 = -1;
+    L.org = L.dir = splat(0);
+    while (__any(L.st != S_DONE)) lane_step<LAMBERT, false>(sv, tx, a.max_depth, spp, x, y, base, L, acc, lc, tc);
+    Accum sum = acc.result();
+    reduce_and_store(a, sum, K, valid && c == 0, x, y, W);
+    flush_counters(a, lc, tc, a.count != 0);
+}
+
+// TILE stream: bit-for-bit the reference's RNG order — one PCG stream per 16x16 tile, pixels y-outer / x-inner,
+// samples innermost (src/render.cpp:281-309). Serial per tile => one lane per tile. For checks.
+template <bool LAMBERT>
+__global__ __launch_bounds__(64) void gdpt_render_tile_stream_phases(DevSceneView sv, KernelArgs a, int ntx, int nty) {
+    __shared__ int s_stack[GDPT_BVH_MAX_DEPTH * 64];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x * 64 + tid;
+    TraceCtx tx = setup_trace<false>(sv, nullptr, s_stack, tid, 64, a.count != 0);
+    LaneCounters lc = {0, 0, 0};
+    TraceCounters tc = {0, 0};
+    const int W = sv.cam.width, H = sv.cam.height;
+    const double spp = (double)a.spp;
+    if (tile < ntx * nty) {
+        const int txi = tile % ntx, tyi = tile / ntx;
+        Lane L;
+        L.rng = pcg_init((unsigned long long)(tyi * ntx + txi));
+        L.k = 0; L.num_vertices = 0; L.cmode = 0; L.mat0 = L.mat1 = -1;
+        L.org = L.dir = splat(0);
+        const int x0 = txi * 16, x1 = min(x0 + 16, W), y0 = tyi * 16, y1 = min(y0 + 16, H);
+        for (int y = y0; y < y1; y++) {
+            if (y < a.row_begin || y >= a.row_end) continue;   // bands are whole tile rows in this mode
+            for (int x = x0; x < x1; x++) {
+                AccReg acc; acc.init();
+                L.s = 0; L.s_end = a.spp; L.st = S_START;
+                while (L.st != S_DONE) lane_step<LAMBERT, true>(sv, tx, a.max_depth, spp, x, y, 0ull, L, acc, lc, tc);
+                Accum sum = acc.result();
+                reduce_and_store(a, sum, 1, true, x, y, W);
+            }
+        }
+    }
+    flush_counters(a, lc, tc, a.count != 0);
+}
+
+#ifdef GDPT_BUILD_EAGER   // only render_eager.hip emits these (non-template) kernels
+// ------------------------------------------------------------------------------------------------
+// eager evaluator (any material set, offsets carried across bounces in private memory)
+// ------------------------------------------------------------------------------------------------
+struct Offset { Vertex v; D3 dir; D3 contrib; double jacob; };
+struct SampleOut { D3 radiance, contrib; D3 cX[4]; double w[4]; double prob; };
+
+GD void zero_out(SampleOut &o) {
+    o.radiance = splat(0); o.contrib = splat(0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { o.cX[k] = splat(0); o.w[k] = 1.0; }
+    o.prob = 1.0;
+}
+
+GD void grad_sample_eager(const DevSceneView &sv, const TraceCtx &tx, int max_depth, int x, int y, Pcg &rng,
+                          SampleOut &out, LaneCounters &lc, TraceCounters &tc) {
+    const DevCamera &cam = sv.cam;
+    const int w = cam.width, h = cam.height;
+    zero_out(out);
+    double rng_x = pcg_real(rng), rng_y = pcg_real(rng);
+    Ray ray = sample_primary(cam, (x + rng_x) / w, (y + rng_y) / h);
+    const double rd_spread = 0.25 / (double)max(w, h);
+    Vertex vertex;
+    if (!intersect_ctx(sv, tx, ray, rd_spread, vertex, lc, tc)) return;
+    Offset off[4];
+    unsigned alive = 0;
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+        int ox = (k == 0) ? -1 : (k == 1 ? 1 : 0), oy = (k == 2) ? 1 : (k == 3 ? -1 : 0);
+        Ray r = sample_primary(cam, ((x + ox) + rng_x) / w, ((y + oy) + rng_y) / h);
+        Vertex ov;
+        bool ok = intersect_ctx(sv, tx, r, rd_spread, ov, lc, tc);
+        if (ok && ov.material_id == vertex.material_id) {
+            alive |= 1u << k;
+            off[k].v = ov; off[k].dir = r.dir; off[k].jacob = 1.0;
+            off[k].contrib = (ov.light_id >= 0) ? emission(sv, ov, -r.dir) : splat(1.0);
+        }
+    }
+    D3 contrib = splat(1.0), throughput = splat(1.0), radiance = splat(0);
+    double prob = 1.0, eta_scale = 1.0;
+    if (vertex.light_id >= 0) { D3 L = emission(sv, vertex, -ray.dir); radiance = L; contrib = L; }
+    for (int num_vertices = 3; loop_allows(max_depth, num_vertices); num_vertices++) {
+        lc.bounces++;
+        const GdptMaterial &mat = sv.materials[vertex.material_id];
+        D3 dir_view = -ray.dir;
+        D2 ruv; ruv.x = pcg_real(rng); ruv.y = pcg_real(rng);
+        double rw = pcg_real(rng);
+        BsdfSample bs;
+        if (!bsdf_sample(sv, mat, dir_view, vertex, ruv, rw, bs)) { zero_out(out); return; }
+        D3 dir_bsdf = bs.dir_out;
+        if (bs.eta != 0) eta_scale /= (bs.eta * bs.eta);
+        Ray bsdf_ray; bsdf_ray.org = vertex.position; bsdf_ray.dir = dir_bsdf; bsdf_ray.tnear = sv.isect_eps; bsdf_ray.tfar = __builtin_huge_val();
+        Vertex bsdf_vertex;
+        bool hit = intersect_ctx(sv, tx, bsdf_ray, 0.0, bsdf_vertex, lc, tc);
+        if (alive) {
+#pragma unroll 1
+            for (int k = 0; k < 4; k++)
+                if ((alive >> k & 1u) && off[k].v.material_id != vertex.material_id) alive &= ~(1u << k);
+        }
+        double G = 1.0;
+        if (hit) { D3 dl = bsdf_vertex.position - vertex.position; G = fabs(dot(dir_bsdf, bsdf_vertex.gn)) / dot(dl, dl); }
+        D3 f = bsdf_eval(sv, mat, dir_view, dir_bsdf, vertex);
+        double p2 = bsdf_pdf(sv, mat, dir_view, dir_bsdf, vertex);
+        if (p2 <= 0) break;
+        p2 *= G;
+        contrib = contrib * f * G;
+        prob *= p2;
+        if (alive) {
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) {
+                if (!(alive >> k & 1u)) continue;
+                Offset &o = off[k];
+                const GdptMaterial &omat = sv.materials[o.v.material_id];
+                D3 oin = -o.dir;
+                BsdfSample os;
+                if (!bsdf_sample(sv, omat, oin, o.v, ruv, rw, os)) { alive &= ~(1u << k); continue; }
+                double p2o = bsdf_pdf(sv, omat, oin, os.dir_out, o.v);
+                if (p2o <= 0.0) { alive &= ~(1u << k); continue; }
+                o.jacob *= p2 / p2o;
+                o.dir = os.dir_out;
+            }
+        }
+        if (hit && bsdf_vertex.light_id >= 0) {
+            D3 L = emission(sv, bsdf_vertex, -dir_bsdf);
+            D3 C2 = (G * f) * L;
+            contrib = contrib * L;
+            radiance = radiance + throughput * (C2 / p2);
+        }
+        if (!hit) break;
+        double rr_prob = 1;
+        if (num_vertices - 1 >= sv.rr_depth) {
+            rr_prob = fmin(maxc((1 / eta_scale) * throughput), 0.95);
+            if (pcg_real(rng) > rr_prob) break;
+        }
+        ray = bsdf_ray;
+        vertex = bsdf_vertex;
+        throughput = throughput * (G * f) / (p2 * rr_prob);
+    }
+    out.radiance = radiance; out.contrib = contrib; out.prob = prob;
+    if (alive) {
+#pragma unroll 1
+        for (int k = 0; k < 4; k++)
+            if (alive >> k & 1u) { out.cX[k] = off[k].contrib * off[k].jacob; out.w[k] = prob / (prob + 1.0 * off[k].jacob); }
+    }
+}
+
+GD void accumulate_eager(AccReg &a, const SampleOut &s, double spp, LaneCounters &lc) {
+    acc_base(a, s.radiance, s.prob, spp, lc);
+    bool flagged = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc_offset(a, k, s.contrib, s.cX[k], s.w[k], s.prob, spp, lc, flagged);
+}
+
+__global__ __launch_bounds__(kBlock) void gdpt_render_eager(DevSceneView sv, KernelArgs a) {
+    __shared__ int s_stack[GDPT_BVH_MAX_DEPTH * kBlock];
+    const int tid = threadIdx.x;
+    TraceCtx tx = setup_trace<false>(sv, nullptr, s_stack, tid, kBlock, a.count != 0);
+    const int K = 1 << a.log2k;
+    const int c = tid & (K - 1), p = tid >> a.log2k;
+    const int px = p % a.tile_w, py = p / a.tile_w;
+    const int bx = blockIdx.x % a.tiles_x, by = blockIdx.x / a.tiles_x;
+    const int x = bx * a.tile_w + px, y = a.row_begin + by * a.tile_h + py;
+    const int W = sv.cam.width;
+    const bool valid = (x < W) && (y < a.row_end);
+    AccReg acc; acc.init();
+    LaneCounters lc = {0, 0, 0};
+    TraceCounters tc = {0, 0};
+    if (valid) {
+        const int s0 = (int)(((long long)c * a.spp) >> a.log2k), s1 = (int)(((long long)(c + 1) * a.spp) >> a.log2k);
+        const unsigned long long base = ((unsigned long long)y * W + x) * (unsigned long long)a.spp;
+        for (int s = s0; s < s1; s++) {
+            Pcg rng = pcg_init(base + (unsigned long long)s);
+            SampleOut so;
+            grad_sample_eager(sv, tx, a.max_depth, x, y, rng, so, lc, tc);
+            accumulate_eager(acc, so, (double)a.spp, lc);
+        }
+    }
+    Accum sum = acc.result();
+    reduce_and_store(a, sum, K, valid && c == 0, x, y, W);
+    flush_counters(a, lc, tc, a.count != 0);
+}
+
+__global__ __launch_bounds__(64) void gdpt_render_tile_stream_eager(DevSceneView sv, KernelArgs a, int ntx, int nty) {
+    __shared__ int s_stack[GDPT_BVH_MAX_DEPTH * 64];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x * 64 + tid;
+    TraceCtx tx = setup_trace<false>(sv, nullptr, s_stack, tid, 64, a.count != 0);
+    LaneCounters lc = {0, 0, 0};
+    TraceCounters tc = {0, 0};
+    const int W = sv.cam.width, H = sv.cam.height;
+    if (tile < ntx * nty) {
+        const int txi = tile % ntx, tyi = tile / ntx;
+        Pcg rng = pcg_init((unsigned long long)(tyi * ntx + txi));
+        const int x0 = txi * 16, x1 = min(x0 + 16, W), y0 = tyi * 16, y1 = min(y0 + 16, H);
+        for (int y = y0; y < y1; y++) {
+            if (y < a.row_begin || y >= a.row_end) continue;
+            for (int x = x0; x < x1; x++) {
+                AccReg acc; acc.init();
+                for (int s = 0; s < a.spp; s++) {
+                    SampleOut so;
+                    grad_sample_eager(sv, tx, a.max_depth, x, y, rng, so, lc, tc);
+                    accumulate_eager(acc, so, (double)a.spp, lc);
+                }
+                Accum sum = acc.result();
+                reduce_and_store(a, sum, 1, true, x, y, W);
+            }
+        }
+    }
+    flush_counters(a, lc, tc, a.count != 0);
+}
+
+#endif // GDPT_BUILD_EAGER
+
+} // namespace gd
+
+namespace gdpt {
+// host launchers, one translation unit per kernel family (parallel compilation)
+void launch_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, int wps, hipStream_t stream);
+void launch_phases_general(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, hipStream_t stream);
+void launch_tile_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
+void launch_tile_phases_general(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
+void launch_eager(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, hipStream_t stream);
+void launch_tile_eager(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
+} // namespace gdpt

@@ -17,7 +17,16 @@ struct RenderLaunch {
     double *img, *cx0, *cy0, *cx1, *cy1;   // device, W*H*3 each
     RenderCounters *counters;      // device
     bool count_traversal;          // counting build: BVH nodes / primitives per ray
+    // scene classification (decided at upload) and tuning knobs
+    bool one_sided_materials;      // no DisneyGlass / DisneyBSDF: the phase machine with lazy offsets is exact
+    bool lambert_only;             // every material is Lambertian
+    bool scene_fits_lds;           // BVH nodes + primitive records fit the block's LDS copy
+    bool force_eager;              // run the eager evaluator regardless (checks / A-B runs)
+    int thresh_a, thresh_c;        // lanes that must wait for phase A / C before a wave runs it (0 = default)
+    int force_log2k;               // lanes per pixel = 2^force_log2k (-1 = automatic)
+    int waves_per_simd;            // register budget variant of the phase kernel (2, 3 or 4)
 };
+bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_materials, int bvh_depth);
 
 // Enqueues the five-buffer render on `stream`. Throws std::runtime_error on a launch failure.
 void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t stream);

@@ -1,0 +1,17 @@
+// Lambertian-only scenes (cbox, sponza): phase-machine kernels with the cosine lobe inlined.
+#include "render_device.h"
+namespace gdpt {
+template <int WPS>
+static void launch_wps(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, hipStream_t stream) {
+    if (lds) hipLaunchKernelGGL((gd::gdpt_render_phases<true, true, WPS>), grid, dim3(gd::kBlock), 0, stream, sv, a);
+    else hipLaunchKernelGGL((gd::gdpt_render_phases<true, false, WPS>), grid, dim3(gd::kBlock), 0, stream, sv, a);
+}
+void launch_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, int wps, hipStream_t stream) {
+    if (wps >= 4) launch_wps<4>(sv, a, grid, lds, stream);
+    else if (wps == 3) launch_wps<3>(sv, a, grid, lds, stream);
+    else launch_wps<2>(sv, a, grid, lds, stream);
+}
+void launch_tile_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream) {
+    hipLaunchKernelGGL((gd::gdpt_render_tile_stream_phases<true>), grid, dim3(64), 0, stream, sv, a, ntx, nty);
+}
+} // namespace gdpt
