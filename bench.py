@@ -23,6 +23,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def host_cores():
+    """CPU share of this process: cgroup quota if there is one, else the affinity mask (capped at 16, the GPU box's
+    per-GPU share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,7 +144,7 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"scenes/cbox/cbox_gdpt.xml Integrator::GradPath {W}x{H}, {args.spp} spp per GPU "
-                               f"({spp_total} spp total), render+assemble+Poisson(CG) per step",
+                               f"({spp_total} spp total), render+assemble+Poisson(DCT-I as fp64 GEMM) per step",
                    "rng": "sample-stream PCG32", "sharding": f"{world} row band(s) + all-gather" if world > 1 else "single GPU",
                    "alpha": args.alpha},
         "render_ms": render_ms_avg, "render_msamples_per_s": samples_rank / render_ms_avg / 1e3 if render_ms_avg > 0 else 0.0,
@@ -146,7 +159,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_py as O
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        cores = host_cores()
         osc = O.OracleScene(sd.ptr, use_bvh=True)
         ob, ost = osc.render(args.cpu_spp, G.RNG_TILE, threads=cores)
         tp = time.perf_counter()

@@ -178,7 +178,7 @@ class Scene:
             pass
 
 
-def fourierSolve(width, height, imgData, imgGradX, imgGradY, dataCost=0.04, solver=defs.SOLVER_CG, tol=0.0,
+def fourierSolve(width, height, imgData, imgGradX, imgGradY, dataCost=0.04, solver=defs.SOLVER_DCT, tol=0.0,
                  max_iters=0, return_stats=False):
     """Screened-Poisson reconstruction on the GPU; arguments as the reference's fourierSolve
     (src/render.cpp:172-175). Inputs HxWx3 (or flat W*H*3) float64; returns HxWx3."""
@@ -195,7 +195,7 @@ def assemble_device(width, height, src_ptrs, dst_ptrs, stream=None):
                                       *[C.c_void_p(int(x)) for x in dst_ptrs], C.c_void_p(int(stream) if stream else 0)))
 
 
-def poisson_solve_device(width, height, c_ptr, gx_ptr, gy_ptr, out_ptr, alpha=0.04, solver=defs.SOLVER_CG, tol=0.0,
+def poisson_solve_device(width, height, c_ptr, gx_ptr, gy_ptr, out_ptr, alpha=0.04, solver=defs.SOLVER_DCT, tol=0.0,
                          max_iters=0, stream=None, want_stats=False):
     st = defs.GdptPoissonStats() if want_stats else None
     _check(lib().gdpt_poisson_solve_device(int(width), int(height), C.c_void_p(int(c_ptr)), C.c_void_p(int(gx_ptr)),

@@ -42,6 +42,9 @@ struct DevTriShade {
     double inv_uv_size;
     int32_t shape_id, prim_id, material_id, light_id; // light_id < 0: not an emitter
     int32_t has_normals, has_uvs;
+    // flat_frame: the three vertex normals are identical (or absent), so the shading frame does not depend on the hit
+    // point beyond rounding: n[0] = tangent, n[1] = bitangent, n[2] = shading normal, evaluated at the barycentre.
+    int32_t flat_frame, pad;
 };
 
 struct DevSphere {

@@ -160,6 +160,17 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     }
 
     gdpt::BvhBuildResult bvh = gdpt::build_bvh(bounds);
+    {   // widen every child box: the traversal's slab test then needs no per-test padding (device_trace.h: box_hit)
+        float ext = 0.f;
+        for (int k = 0; k < 3; k++) if (ub[k] >= lb[k]) ext = std::max(ext, std::max(std::fabs(ub[k]), std::fabs(lb[k])));
+        for (auto &sp : spheres) for (int k = 0; k < 3; k++) ext = std::max(ext, (float)(std::fabs(sp.center[k]) + sp.radius));
+        const float pad = ext * 1e-6f + 1e-30f;
+        for (auto &n : bvh.nodes)
+            for (int k = 0; k < 3; k++) {
+                if (n.lmin[k] <= n.lmax[k]) { n.lmin[k] -= pad; n.lmax[k] += pad; }
+                if (n.rmin[k] <= n.rmax[k]) { n.rmin[k] -= pad; n.rmax[k] += pad; }
+            }
+    }
     std::vector<DevPrim> prims(prim_in.size());
     for (size_t i = 0; i < bvh.order.size(); i++) prims[i] = prim_in[bvh.order[i]];
     sc->bvh_depth = bvh.depth;
@@ -398,7 +409,7 @@ int gdpt_poisson_solve_ex(int width, int height, const double *imgData, const do
 
 int gdpt_poisson_solve(int width, int height, const double *imgData, const double *imgGradX, const double *imgGradY,
                        double dataCost, double *imgOut) {
-    return gdpt_poisson_solve_ex(width, height, imgData, imgGradX, imgGradY, dataCost, imgOut, GDPT_SOLVER_CG, 0.0, 0, nullptr);
+    return gdpt_poisson_solve_ex(width, height, imgData, imgGradX, imgGradY, dataCost, imgOut, GDPT_SOLVER_DCT, 0.0, 0, nullptr);
 }
 
 int gdpt_gradient_path_render(GdptScene *scene, const GdptRenderParams *params, double dataCost, double *out_image,
@@ -416,7 +427,7 @@ int gdpt_gradient_path_render(GdptScene *scene, const GdptRenderParams *params, 
         GdptRenderStats local{};
         render_device_impl(scene, &p, scene->scene_spp, b[0], b[1], b[2], b[3], b[4], nullptr, rstats ? rstats : &local);
         gdpt::launch_assemble(w, h, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], nullptr);
-        gdpt::PoissonResult r = gdpt::poisson_solve_device(w, h, b[5], b[6], b[7], dataCost, b[8], GDPT_SOLVER_CG, 0.0, 0, nullptr);
+        gdpt::PoissonResult r = gdpt::poisson_solve_device(w, h, b[5], b[6], b[7], dataCost, b[8], GDPT_SOLVER_DCT, 0.0, 0, nullptr);
         if (pstats) { pstats->iterations = r.iterations; pstats->solver = r.solver; pstats->rel_residual = r.rel_residual; pstats->solve_ms = r.solve_ms; }
         ck(hipMemcpy(out_image, b[8], elems * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
         double *host[5] = {img, cx0, cy0, cx1, cy1};

@@ -74,10 +74,10 @@ GD double tex1(const DevSceneView &sv, const GdptTexture &t, const Vertex &vx) {
 
 // ---- helpers ------------------------------------------------------------------------------------
 GD D3 sample_cos_hemisphere(D2 r) { // src/material.cpp:4-11
-    double phi = kTwoPi * r.x;
+    // phi = 2*pi*u: sincospi(2u) skips the large-argument reduction of sincos (the two differ by the rounding of phi)
     double tmp = sqrt(clamp01(1 - r.y));
     double s, c;
-    sincos(phi, &s, &c);
+    sincospi(2.0 * r.x, &s, &c);
     return mk(c * tmp, s * tmp, sqrt(clamp01(r.y)));
 }
 GD double fresnel_dielectric2(double n_dot_i, double n_dot_t, double eta) { // src/microfacet.h:34-40
@@ -95,9 +95,8 @@ GD D3 sample_visible_normals(D3 local_in, double ax, double ay, D2 rnd) { // src
     if (flip) local_in = -local_in;
     D3 hemi = normalize(mk(ax * local_in.x, ay * local_in.y, local_in.z));
     double r = sqrt(rnd.x);
-    double phi = 2 * kPi * rnd.y;
     double sp, cp;
-    sincos(phi, &sp, &cp);
+    sincospi(2.0 * rnd.y, &sp, &cp);
     double t1 = r * cp, t2 = r * sp;
     double s = (1 + hemi.z) / 2;
     t2 = (1 - s) * sqrt(1 - t1 * t1) + s * t2;
@@ -113,7 +112,7 @@ GD D3 sample_clearcoat_normal(double alpha, D2 rnd) { // src/microfacet.h:164-17
     double sin_e = sqrt((pw - a2) / (1 - a2));
     double cos_e = sqrt((1 - pw) / (1 - a2));
     double s, c;
-    sincos(2 * kPi * rnd.y, &s, &c);
+    sincospi(2.0 * rnd.y, &s, &c);
     return normalize(mk(sin_e * c, sin_e * s, cos_e));
 }
 

@@ -12,7 +12,7 @@ namespace gd {
 
 struct Hit { float t, u, v, ngx, ngy, ngz; int gid; };   // gid < 0: miss
 
-struct TraceCounters { unsigned long long nodes, prims; };
+struct TraceCounters { unsigned nodes, prims; };   // per lane; summed in 64 bits across the wave
 
 // fp32 Moller-Trumbore, two-sided; every operation rounds once (no FMA contraction), sums left to right.
 // The CPU checker used by the tests restates exactly this arithmetic.
@@ -38,7 +38,9 @@ GD bool tri_hit(const float o[3], const float d[3], float tnear, float tfar, con
 }
 
 // Sphere primitive: fp64 quadratic on the fp32 ray (src/shapes/sphere.inl:15-106).
-GD bool sphere_hit(const float o[3], const float d[3], float tnear, float tfar, const DevSphere &sp, Hit &h) {
+// Kept out of line: spheres are rare (an emitter or two), and inlining this fp64 block into the traversal loop would
+// raise the register pressure of every triangle-only ray.
+__device__ __noinline__ bool sphere_hit(const float *o, const float *d, float tnear, float tfar, const DevSphere &sp, Hit &h) {
 #pragma clang fp contract(off)
     double ox = o[0] - sp.center[0], oy = o[1] - sp.center[1], oz = o[2] - sp.center[2];
     double dx = d[0], dy = d[1], dz = d[2];
@@ -89,19 +91,18 @@ GD void test_prim(const DevSceneView &sv, const DevPrim &pr, const float o[3], c
     }
 }
 
-// Conservative slab test: returns entry distance in `tin`; never rejects a box that holds a primitive
-// able to report t <= tbest.
+// Slab test against boxes the host has already widened (gdpt_scene_upload pads every child box by 1e-6 of the scene
+// extent, which dominates the rounding of (bound - origin)); the remaining relative error of the products is
+// absorbed by the 1e-6 slack on the exit distance. Never rejects a box holding a primitive that can report t <= tbest.
 GD bool box_hit(const float *mn, const float *mx, const float o[3], const float inv[3], float tnear, float tbest, float &tin) {
     float t0 = tnear, t1 = tbest;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float a = (mn[k] - o[k]) * inv[k], b = (mx[k] - o[k]) * inv[k];
-        float lo = fminf(a, b), hi = fmaxf(a, b);       // NaN (0*inf on flat boxes) is dropped by fmin/fmax
-        lo = lo - fabsf(lo) * 4e-7f; hi = hi + fabsf(hi) * 4e-7f;
-        t0 = fmaxf(t0, lo); t1 = fminf(t1, hi);
+        t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));       // NaN (0*inf on flat boxes) is dropped by fmin/fmax
     }
     tin = t0;
-    return t0 <= t1;
+    return t0 <= t1 * 1.000001f;
 }
 
 // `stack` points at this lane's slot 0 in LDS; consecutive levels are `stride` ints apart
@@ -156,6 +157,13 @@ GD void shading_info_tri(const DevTriShade &ts, D2 st, D3 gn, bool need_uv, D2 &
         uv.x = b0 * ts.uv[0][0] + st.x * ts.uv[1][0] + st.y * ts.uv[2][0];
         uv.y = b0 * ts.uv[0][1] + st.x * ts.uv[1][1] + st.y * ts.uv[2][1];
     } else { uv.x = uv.y = 0; }
+    inv_uv_size = ts.inv_uv_size;
+    if (ts.flat_frame) {
+        // identical vertex normals: the frame is a per-triangle constant (host-evaluated at the barycentre; the
+        // reference's per-hit value differs from it only by the rounding of (1-s-t)*n + s*n + t*n)
+        frame.x = mk(ts.n[0][0], ts.n[0][1], ts.n[0][2]); frame.y = mk(ts.n[1][0], ts.n[1][1], ts.n[1][2]); frame.n = mk(ts.n[2][0], ts.n[2][1], ts.n[2][2]);
+        return;
+    }
     D3 dpdu = mk(ts.dpdu[0], ts.dpdu[1], ts.dpdu[2]);
     D3 sn = gn;
     if (ts.has_normals) {
@@ -165,7 +173,6 @@ GD void shading_info_tri(const DevTriShade &ts, D2 st, D3 gn, bool need_uv, D2 &
     D3 tangent = normalize(dpdu - sn * dot(sn, dpdu));
     D3 bitangent = normalize(cross(sn, tangent));
     frame.x = tangent; frame.y = bitangent; frame.n = sn;
-    inv_uv_size = ts.inv_uv_size;
 }
 
 GD void shading_info_sphere(const DevSphere &sp, D2 st, D3 gn, D2 &uv, Frame &frame, double &inv_uv_size) {
@@ -227,7 +234,7 @@ GD D2 filter_sample(int type, double param, double rx, double ry) {
     else if (type == GDPT_FILTER_GAUSSIAN) {
         double r = param * sqrt(-2 * log(fmax(rx, 1e-8)));
         double s, c;
-        sincos(2 * kPi * ry, &s, &c);
+        sincospi(2.0 * ry, &s, &c);
         o.x = r * c; o.y = r * s;
     } else {
         double h = param / 2;
@@ -247,10 +254,18 @@ GD D3 xform_point(const double *m, D3 p) {
 GD D3 xform_vector(const double *m, D3 v) {
     return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
 }
-GD Ray sample_primary(const DevCamera &cam, double sx, double sy) {
+// `cache` (optional): the sub-pixel numbers (dx,dy) and filter offset of the lane's base ray. An offset ray whose
+// (dx,dy) are bit-identical (always, for power-of-two film sizes) reuses the offset instead of re-evaluating the filter.
+struct FilterCache { double dx, dy, ox, oy; };
+GD Ray sample_primary(const DevCamera &cam, double sx, double sy, FilterCache *cache = nullptr, bool store = false) {
     double ppx = sx * cam.width, ppy = sy * cam.height;
     double fx = floor(ppx), fy = floor(ppy);
-    D2 off = filter_sample(cam.filter_type, cam.filter_param, ppx - fx, ppy - fy);
+    D2 off;
+    if (cache && !store && cache->dx == ppx - fx && cache->dy == ppy - fy) { off.x = cache->ox; off.y = cache->oy; }
+    else {
+        off = filter_sample(cam.filter_type, cam.filter_param, ppx - fx, ppy - fy);
+        if (cache && store) { cache->dx = ppx - fx; cache->dy = ppy - fy; cache->ox = off.x; cache->oy = off.y; }
+    }
     double rx = (fx + 0.5 + off.x) / cam.width, ry = (fy + 0.5 + off.y) / cam.height;
     D3 pt = xform_point(cam.sample_to_cam, mk(rx, ry, 0.0));
     D3 dir = normalize(pt);

@@ -20,8 +20,11 @@
 #include "poisson_kernels.h"
 #include "../../../include/gdpt.h"
 
+#include <rocblas/rocblas.h>
+
 #include <chrono>
 #include <cmath>
+#include <vector>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -197,6 +200,63 @@ __global__ __launch_bounds__(kBlock) void cg_finalize_kernel(Geo g, double alpha
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Direct solver: the reference's own algorithm (src/render.cpp:172-254) with FFTW's REDFT00 replaced by its
+// definition as a dense product, Y[k] = sum_j w_j X[j] cos(pi j k/(n-1)) (w = 1 at the ends, 2 inside), i.e.
+//     H^ = Ch^T * H * Cw,   C[j][k] = w_j cos(pi j k/(n-1))
+// evaluated with fp64 GEMMs (MFMA via rocBLAS) on channel-planar buffers. Includes the fp32-rounded Laplacian
+// eigenvalue (:233) and the DC override (:239), so it matches the reference operator exactly.
+// ------------------------------------------------------------------------------------------------
+// planar h[c][y][x] = alpha*u - D(g) (:213-224); partials[c*nb + b] = block partial of sum(w*u) per channel
+__global__ __launch_bounds__(kBlock) void dct_rhs_kernel(Geo g, double alpha, const double *u, const double *gx, const double *gy,
+                                                         double *hplanar, double *partials) {
+    __shared__ double red[kBlock / 64];
+    const int plane = g.w * g.h;
+    double s_wu[3] = {0, 0, 0};
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < g.n3; i += gridDim.x * kBlock) {
+        int y = i / g.row, col = i - y * g.row, xx = col / 3, ch = col - xx * 3;
+        double ui = u[i];
+        double hv = alpha * ui;
+        if (xx > 0 && xx < g.w - 1) hv -= (gx[i + 3] - gx[i]); else hv -= (-2.0 * gx[i]);
+        if (y > 0 && y < g.h - 1) hv -= (gy[i + g.row] - gy[i]); else hv -= (-2.0 * gy[i]);
+        hplanar[(size_t)ch * plane + (size_t)y * g.w + xx] = hv;
+        double wgt = weight(g, xx, y);
+#pragma unroll
+        for (int k = 0; k < 3; k++) if (ch == k) s_wu[k] += wgt * ui;
+    }
+    const int nb = gridDim.x;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { double v = block_sum(s_wu[k], red); if (threadIdx.x == 0) partials[k * nb + blockIdx.x] = v; }
+}
+// F^ = H^ / (alpha - (float)(lapY[y] + lapX[x]))  (:229-235)
+__global__ __launch_bounds__(kBlock) void dct_scale_kernel(Geo g, double alpha, const double *lap_x, const double *lap_y, double *hhat) {
+    const int plane = g.w * g.h;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < 3 * plane; i += gridDim.x * kBlock) {
+        int r = i % plane, y = r / g.w, xx = r - y * g.w;
+        float resp = (float)(lap_y[y] + lap_x[xx]);          // `float ftLapResponse` in the reference
+        hhat[i] = hhat[i] / (alpha - resp);
+    }
+}
+// F^[0,0] := sum(w*u) per channel (:239), after the scaling pass
+__global__ void dct_dc_kernel(Geo g, double *hhat, const double *partials, int nb) {
+    __shared__ double red[kBlock / 64];
+    const int plane = g.w * g.h;
+    for (int c = 0; c < 3; c++) {
+        double dc = reduce_partials(partials + c * nb, nb, red);
+        __syncthreads();
+        if (threadIdx.x == 0) hhat[(size_t)c * plane] = dc;
+    }
+}
+__global__ __launch_bounds__(kBlock) void dct_finalize_kernel(Geo g, const double *fplanar, double *out) {
+    const int plane = g.w * g.h;
+    const double denom = 4.0 * (double)(g.w - 1) * (double)(g.h - 1);
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < g.n3; i += gridDim.x * kBlock) {
+        int p = i / 3, ch = i - p * 3;
+        out[i] = fplanar[(size_t)ch * plane + p] / denom;      // :245-247
+    }
+}
+
 } // namespace gp
 
 namespace gdpt {
@@ -240,9 +300,123 @@ std::mutex g_ws_mu;
 
 } // namespace
 
+
+// ---- direct DCT-I solver (GEMM) ---------------------------------------------------------------------
+namespace {
+
+struct DctPlan {
+    int n = 0;
+    double *d_mat = nullptr;   // C[j][k] = w_j cos(pi j k/(n-1)), row-major n x n
+    double *d_lap = nullptr;   // 2 cos(pi i/(n-1)) (the caller adds -4 on the y axis)
+};
+struct DctWorkspace {
+    int device = -1;
+    rocblas_handle handle = nullptr;
+    DctPlan plans[2];          // [0] width, [1] height (same plan object when w == h is handled by lookup)
+    size_t elems = 0;
+    double *buf[2] = {nullptr, nullptr};
+    double *partials = nullptr;
+    double *lap_y = nullptr; int lap_y_n = 0;
+    void release() {
+        for (auto &p : plans) { if (p.d_mat) hipFree(p.d_mat); if (p.d_lap) hipFree(p.d_lap); p = DctPlan(); }
+        for (auto &b : buf) { if (b) hipFree(b); b = nullptr; }
+        if (partials) hipFree(partials);
+        if (lap_y) hipFree(lap_y);
+        if (handle) rocblas_destroy_handle(handle);
+        *this = DctWorkspace();
+    }
+};
+DctWorkspace g_dct;
+
+void rb(rocblas_status st, const char *what) {
+    if (st != rocblas_status_success) throw std::runtime_error(std::string(what) + ": rocBLAS status " + std::to_string((int)st));
+}
+
+// host tables, with the argument reduced exactly: cos(pi * ((j*k) mod 2(n-1)) / (n-1))
+void build_plan(DctPlan &p, int n) {
+    if (p.n == n) return;
+    if (p.d_mat) hipFree(p.d_mat);
+    if (p.d_lap) hipFree(p.d_lap);
+    p = DctPlan();
+    std::vector<double> m((size_t)n * n), lap(n), ctab(2 * (size_t)(n - 1));
+    for (size_t i = 0; i < ctab.size(); i++) ctab[i] = std::cos(M_PI * (double)i / (double)(n - 1));
+    for (int j = 0; j < n; j++) {
+        double wj = (j > 0 && j < n - 1) ? 2.0 : 1.0;
+        for (int k = 0; k < n; k++) m[(size_t)j * n + k] = wj * ctab[((size_t)j * k) % ctab.size()];
+    }
+    for (int i = 0; i < n; i++) lap[i] = 2.0 * std::cos(M_PI * i / (n - 1));     // ftLapX (:184-186)
+    ck(hipMalloc((void **)&p.d_mat, m.size() * sizeof(double)), "hipMalloc(dct matrix)");
+    ck(hipMalloc((void **)&p.d_lap, lap.size() * sizeof(double)), "hipMalloc(dct lap)");
+    ck(hipMemcpy(p.d_mat, m.data(), m.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(dct matrix)");
+    ck(hipMemcpy(p.d_lap, lap.data(), lap.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(dct lap)");
+    p.n = n;
+}
+
+PoissonResult poisson_dct(int w, int h, const double *d_c, const double *d_gx, const double *d_gy, double alpha,
+                          double *d_out, hipStream_t stream) {
+    int dev = 0;
+    ck(hipGetDevice(&dev), "hipGetDevice");
+    DctWorkspace &ws = g_dct;
+    if (ws.device != dev) { ws.release(); ws.device = dev; }
+    if (!ws.handle) rb(rocblas_create_handle(&ws.handle), "rocblas_create_handle");
+    rb(rocblas_set_stream(ws.handle, stream), "rocblas_set_stream");
+    build_plan(ws.plans[0], w);
+    build_plan(ws.plans[1], h);
+    gp::Geo g{w, h, w * h * 3, w * 3};
+    const size_t plane = (size_t)w * h;
+    if (ws.elems < 3 * plane) {
+        for (auto &b : ws.buf) { if (b) hipFree(b); b = nullptr; }
+        for (auto &b : ws.buf) ck(hipMalloc((void **)&b, 3 * plane * sizeof(double)), "hipMalloc(dct buffers)");
+        ws.elems = 3 * plane;
+    }
+    if (!ws.partials) ck(hipMalloc((void **)&ws.partials, 3 * gp::kMaxBlocks * sizeof(double)), "hipMalloc(dct partials)");
+    if (ws.lap_y_n != h) {   // ftLapY = -4 + 2 cos(pi y/(h-1)) (:187-189)
+        if (ws.lap_y) hipFree(ws.lap_y);
+        std::vector<double> ly(h);
+        for (int y = 0; y < h; y++) ly[y] = -4.0 + (2.0 * std::cos(M_PI * y / (h - 1)));
+        ck(hipMalloc((void **)&ws.lap_y, h * sizeof(double)), "hipMalloc(lap_y)");
+        ck(hipMemcpy(ws.lap_y, ly.data(), h * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(lap_y)");
+        ws.lap_y_n = h;
+    }
+    const int nb = std::min(gp::kMaxBlocks, (g.n3 + gp::kBlock - 1) / gp::kBlock);
+    hipEvent_t e0, e1;
+    ck(hipEventCreate(&e0), "hipEventCreate"); ck(hipEventCreate(&e1), "hipEventCreate");
+    ck(hipEventRecord(e0, stream), "hipEventRecord");
+    double *A = ws.buf[0], *B = ws.buf[1];
+    hipLaunchKernelGGL(gp::dct_rhs_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, alpha, d_c, d_gx, d_gy, A, ws.partials);
+    const double one = 1.0, zero = 0.0;
+    const double *Cw = ws.plans[0].d_mat, *Ch = ws.plans[1].d_mat;
+    // Row-major X (h x w) is the column-major matrix X^T (w x h, ld = w). Row transform T = X * Cw  <=>  T^T = Cw^T * X^T:
+    // the row-major buffer of Cw read column-major IS Cw^T, so (N, N). Column transform Y = Ch^T * T  <=>  Y^T = T^T * Ch:
+    // the buffer of Ch read column-major is Ch^T, hence op = T on it.
+    auto transform = [&](const double *src, double *tmp, double *dst) {
+        rb(rocblas_dgemm_strided_batched(ws.handle, rocblas_operation_none, rocblas_operation_none, w, h, w, &one,
+                                         Cw, w, 0, src, w, (rocblas_stride)plane, &zero, tmp, w, (rocblas_stride)plane, 3), "dgemm(rows)");
+        rb(rocblas_dgemm_strided_batched(ws.handle, rocblas_operation_none, rocblas_operation_transpose, w, h, h, &one,
+                                         tmp, w, (rocblas_stride)plane, Ch, h, 0, &zero, dst, w, (rocblas_stride)plane, 3), "dgemm(cols)");
+    };
+    transform(A, B, A);                                      // A = DCT2D(h)
+    hipLaunchKernelGGL(gp::dct_scale_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, alpha, ws.plans[0].d_lap, ws.lap_y, A);
+    hipLaunchKernelGGL(gp::dct_dc_kernel, dim3(1), dim3(gp::kBlock), 0, stream, g, A, ws.partials, nb);
+    transform(A, B, A);                                      // A = DCT2D(F^)
+    hipLaunchKernelGGL(gp::dct_finalize_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, A, d_out);
+    ck(hipGetLastError(), "dct kernel launch");
+    ck(hipEventRecord(e1, stream), "hipEventRecord");
+    ck(hipEventSynchronize(e1), "hipEventSynchronize");
+    float ms = 0;
+    ck(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    PoissonResult res;
+    res.iterations = 0; res.solver = GDPT_SOLVER_DCT; res.rel_residual = 0.0; res.solve_ms = ms;
+    return res;
+}
+
+} // namespace
+
 void poisson_release_workspace() {
     std::lock_guard<std::mutex> lk(g_ws_mu);
     g_ws.release();
+    g_dct.release();
 }
 
 void launch_assemble(int w, int h, const double *img, const double *cx0, const double *cy0, const double *cx1, const double *cy1,
@@ -257,11 +431,12 @@ void launch_assemble(int w, int h, const double *img, const double *cx0, const d
 PoissonResult poisson_solve_device(int w, int h, const double *d_c, const double *d_gx, const double *d_gy, double alpha,
                                    double *d_out, int solver, double tol, int max_iters, hipStream_t stream) {
     if (w < 2 || h < 2) throw std::runtime_error("poisson: width and height must be >= 2 (the reference divides by (W-1)(H-1))");
-    if (!(alpha > 0)) throw std::runtime_error("poisson: dataCost must be > 0 for the CG solver");
-    if (solver != GDPT_SOLVER_CG) throw std::runtime_error("poisson: only GDPT_SOLVER_CG is built in this round");
+    if (!(alpha > 0)) throw std::runtime_error("poisson: dataCost must be > 0");
+    if (solver != GDPT_SOLVER_CG && solver != GDPT_SOLVER_DCT) throw std::runtime_error("poisson: unknown solver");
     if (tol <= 0) tol = 1e-10;
     if (max_iters <= 0) max_iters = 2000;
     std::lock_guard<std::mutex> lk(g_ws_mu);
+    if (solver == GDPT_SOLVER_DCT) return poisson_dct(w, h, d_c, d_gx, d_gy, alpha, d_out, stream);
     gp::Geo g{w, h, w * h * 3, w * 3};
     g_ws.ensure((size_t)g.n3);
     Workspace &ws = g_ws;

@@ -37,8 +37,8 @@
 namespace gd {
 
 constexpr int kBlock = 256;
-constexpr int kLdsSceneBytes = 24 * 1024;     // nodes + prims + shading table + materials of a "small" scene
-constexpr int kLdsSceneLevels = 16;           // stack slots per lane when the scene is LDS-resident
+constexpr int kLdsSceneBytes = 20 * 1024;     // nodes + prims + shading table + materials of a "small" scene
+constexpr int kLdsSceneLevels = 12;           // stack slots per lane when the scene is LDS-resident
 
 struct LaneCounters { unsigned rays, bounces, nonfinite; };
 struct Accum { D3 r, dx0, dy0, dx1, dy1; };
@@ -155,6 +155,7 @@ GD Hit closest_hit_ctx(const DevSceneView &sv, const TraceCtx &tx, const float o
         } else {
             unsigned packed = ~(unsigned)cur;
             unsigned first = packed >> 2, cnt = (packed & 3u) + 1u;
+#pragma unroll 1
             for (unsigned i = 0; i < cnt; i++) {
                 if (tx.count) tc.prims++;
                 test_prim(sv, tx.prims[first + i], o, d, tnear, tfar, best);
@@ -225,24 +226,42 @@ enum { C_NO_LOOP = 0,        // the bounce loop never ran (max_depth < 2): jacob
        C_BROKE_BOUNCE1 = 2,  // p2 <= 0 in bounce 1 (break before the offsets' re-sampling): jacobian 1
        C_BROKE_BOUNCE2 = 3 };// p2 <= 0 in bounce 2: bounce-1 jacobian (bounce 2's material test already passed)
 
+// Cold per-lane fields live in a private LDS slot (a "manual spill" that costs an LDS access instead of a scratch
+// round trip): radiance (touched on emitter hits and when a sample is finished), p2_1 and the filter cache
+// (offset phase only).  Layout: slot[c * stride], c = 0..2 radiance, 3 p2_1, 4..7 filter cache (dx, dy, ox, oy).
+struct LanePriv {
+    double *slot; int stride;
+    GD D3 radiance() const { return mk(slot[0], slot[stride], slot[2 * stride]); }
+    GD void set_radiance(D3 v) { slot[0] = v.x; slot[stride] = v.y; slot[2 * stride] = v.z; }
+    GD double p2_1() const { return slot[3 * stride]; }
+    GD void set_p2_1(double v) { slot[3 * stride] = v; }
+    GD FilterCache fc() const { FilterCache f; f.dx = slot[4 * stride]; f.dy = slot[5 * stride]; f.ox = slot[6 * stride]; f.oy = slot[7 * stride]; return f; }
+    GD void set_fc(const FilterCache &f) { slot[4 * stride] = f.dx; slot[5 * stride] = f.dy; slot[6 * stride] = f.ox; slot[7 * stride] = f.oy; }
+};
+constexpr int kPrivDoubles = 8;
+
 struct Lane {
-    int st, k, s, s_end;
-    int mat0, mat1, cmode, num_vertices;
-    Pcg rng;
+    int st, s, s_end, num_vertices;
+    int mats;                 // mat0 | mat1 << 12 (material ids of the base primary hit / the bounce-1 hit), 0xFFF = none
+    int kc;                   // offset index k | cmode << 2
+    unsigned long long rng_state, rng_inc;
     D3 org, dir;              // the pending ray
     D3 f; double pdf;         // S_BOUNCE: f*|cos| and solid-angle pdf of `dir` at the vertex the ray leaves
-    D3 contrib, throughput, radiance;
-    double prob, eta_scale;
-    double p2_1;              // base p2 (incl. G) of bounce 1
+    D3 contrib, throughput;
+    double prob;
     double rng_x, rng_y;      // serial-RNG (TILE) mode only: the sample's sub-pixel and bounce-1 numbers
     D2 ruv1; double rw1;      // (SAMPLE mode re-derives them from the sample's own PCG stream)
+    GD int mat0() const { return mats & 0xFFF; }
+    GD int mat1() const { return (mats >> 12) & 0xFFF; }
+    GD int k() const { return kc & 3; }
+    GD int cmode() const { return kc >> 2; }
 };
 
 // SERIAL_RNG: one PCG stream runs through consecutive samples (TILE scheme); otherwise each sample owns stream
 // `base + s` (SAMPLE scheme) and its sub-pixel / bounce-1 numbers are re-derived from it when an offset needs them.
 template <bool LAMBERT, bool SERIAL_RNG, class ACC>
 GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, double spp, int x, int y, unsigned long long base,
-                  Lane &L, ACC &acc, LaneCounters &lc, TraceCounters &tc) {
+                  Lane &L, LanePriv &lp, ACC &acc, LaneCounters &lc, TraceCounters &tc) {
     const DevCamera &cam = sv.cam;
     const int w = cam.width, h = cam.height;
     const int st0 = L.st;
@@ -261,12 +280,14 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
     } else if (st0 == S_PRIMARY) {
         if (!hit) act = ACT_NEXT_SAMPLE;                                            // :375-379: zero record, adds nothing
         else {
-            L.mat0 = nv.material_id; L.mat1 = -1;
-            L.contrib = splat(1.0); L.throughput = splat(1.0); L.radiance = splat(0);
-            L.prob = 1.0; L.eta_scale = 1.0; L.p2_1 = 1.0;
-            if (nv.light_id >= 0) { D3 Le = emission(sv, nv, -ray.dir); L.radiance = Le; L.contrib = Le; }   // :490-493
+            L.mats = (nv.material_id & 0xFFF) | (0xFFF << 12);
+            L.contrib = splat(1.0); L.throughput = splat(1.0);
+            L.prob = 1.0;
+            D3 rad0 = splat(0);
+            if (nv.light_id >= 0) { D3 Le = emission(sv, nv, -ray.dir); rad0 = Le; L.contrib = Le; }   // :490-493
+            lp.set_radiance(rad0); lp.set_p2_1(1.0);
             L.num_vertices = 3;
-            if (!loop_allows(max_depth, 3)) { L.cmode = C_NO_LOOP; act = ACT_OFFSETS; } else act = ACT_BOUNCE;
+            if (!loop_allows(max_depth, 3)) { L.kc = C_NO_LOOP << 2; act = ACT_OFFSETS; } else act = ACT_BOUNCE;
         }
     } else if (st0 == S_BOUNCE) {
         const bool first = (L.num_vertices == 3);
@@ -275,85 +296,92 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
         const D3 f = L.f;
         double p2 = L.pdf * G;                                                      // :766
         L.contrib = L.contrib * f * G; L.prob *= p2;                                // :769-770
-        if (first) L.p2_1 = p2;
+        if (first) lp.set_p2_1(p2);
         if (hit && nv.light_id >= 0) {                                              // :971-980
             D3 Le = emission(sv, nv, -ray.dir);
             D3 C2 = (G * f) * Le;
             L.contrib = L.contrib * Le;
-            L.radiance = L.radiance + L.throughput * (C2 / p2);
+            lp.set_radiance(lp.radiance() + L.throughput * (C2 / p2));
         }
         bool stop = !hit;                                                           // :982-985
         if (!stop) {
             double rr_prob = 1;
             if (L.num_vertices - 1 >= sv.rr_depth) {                                // :992-999
-                rr_prob = fmin(maxc((1 / L.eta_scale) * L.throughput), 0.95);
-                if (pcg_real(L.rng) > rr_prob) stop = true;
+                rr_prob = fmin(maxc(1.0 * L.throughput), 0.95);                    // eta_scale == 1: one-sided lobes never refract
+                Pcg rr_rng; rr_rng.state = L.rng_state; rr_rng.inc = L.rng_inc;
+                double u = pcg_real(rr_rng); L.rng_state = rr_rng.state;
+                if (u > rr_prob) stop = true;
             }
             if (!stop) {
                 L.throughput = L.throughput * (G * f) / (p2 * rr_prob);             // :1003
                 L.num_vertices++;
-                if (first) L.mat1 = nv.material_id;
+                if (first) L.mats = (L.mats & 0xFFF) | ((nv.material_id & 0xFFF) << 12);
                 if (!loop_allows(max_depth, L.num_vertices)) stop = true;
             }
         }
         if (!stop) act = ACT_BOUNCE;
-        else if (first) { L.cmode = C_AFTER_BOUNCE1; act = ACT_OFFSETS; }
-        else { acc_no_offsets(acc, L.radiance, L.contrib, L.prob, spp, lc); act = ACT_NEXT_SAMPLE; }
+        else if (first) { L.kc = C_AFTER_BOUNCE1 << 2; act = ACT_OFFSETS; }
+        else { acc_no_offsets(acc, lp.radiance(), L.contrib, L.prob, spp, lc); act = ACT_NEXT_SAMPLE; }
         // (one-sided lobes: offsets alive after bounce 1 are retired by bounce 2's re-sampling, see file header)
-    } else if (st0 == S_OFFSET) {
-        const int k = L.k;
+    }
+    // ---------------- shared BSDF block: sample a direction at `nv` and evaluate f / pdf there ----------------
+    // Needed by (a) base lanes that start a bounce iteration at nv and (b) offset lanes whose vertex nv is re-sampled
+    // with the base path's bounce-1 numbers (:773-959). One copy of the code, run by both groups together.
+    const bool off_valid = (st0 == S_OFFSET) && hit && nv.material_id == L.mat0();                   // :424-443
+    const bool off_resample = off_valid && (L.cmode() == C_AFTER_BOUNCE1 || L.cmode() == C_BROKE_BOUNCE2);
+    bool sampled = false;
+    BsdfSample bs; bs.dir_out = splat(0); bs.eta = 0; bs.roughness = 0;
+    D3 f = splat(0);
+    double pdf = 0;
+    if (act == ACT_BOUNCE || off_resample) {
+        D2 ruv; double rw;
+        if (act == ACT_BOUNCE) {
+            lc.bounces++;
+            Pcg r; r.state = L.rng_state; r.inc = L.rng_inc;
+            ruv.x = pcg_real(r); ruv.y = pcg_real(r); rw = pcg_real(r);                              // :536-537
+            L.rng_state = r.state;
+            if (SERIAL_RNG && L.num_vertices == 3) { L.ruv1 = ruv; L.rw1 = rw; }
+        } else if (SERIAL_RNG) { ruv = L.ruv1; rw = L.rw1; }
+        else {
+            Pcg r2 = pcg_init(base + (unsigned long long)L.s);
+            (void)pcg_next(r2); (void)pcg_next(r2);
+            ruv.x = pcg_real(r2); ruv.y = pcg_real(r2); rw = pcg_real(r2);
+        }
+        const D3 dir_view = -ray.dir;
+        sampled = mat_sample<LAMBERT>(sv, tx, nv, dir_view, ruv, rw, bs);
+        if (sampled) mat_eval_pdf<LAMBERT>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
+    }
+    if (st0 == S_OFFSET) {
+        const int k = L.k();
         D3 cX = splat(0);
         double wgt = 1.0;
-        if (hit && nv.material_id == L.mat0) {                                      // :424-443
+        if (off_valid) {
             D3 c0 = (nv.light_id >= 0) ? emission(sv, nv, -ray.dir) : splat(1.0);   // :496-508
             double jac = 1.0;
             bool alive = true;
-            if (L.cmode == C_AFTER_BOUNCE1 || L.cmode == C_BROKE_BOUNCE2) {         // :773-959: re-sampled with the base's numbers
-                D2 ruv1; double rw1;
-                if (SERIAL_RNG) { ruv1 = L.ruv1; rw1 = L.rw1; }
-                else {
-                    Pcg r2 = pcg_init(base + (unsigned long long)L.s);
-                    (void)pcg_next(r2); (void)pcg_next(r2);
-                    ruv1.x = pcg_real(r2); ruv1.y = pcg_real(r2); rw1 = pcg_real(r2);
-                }
-                D3 oin = -ray.dir;
-                BsdfSample os;
-                if (!mat_sample<LAMBERT>(sv, tx, nv, oin, ruv1, rw1, os)) alive = false;
-                else {
-                    double p2o = mat_pdf<LAMBERT>(sv, tx, nv, oin, os.dir_out);
-                    if (p2o <= 0.0) alive = false; else jac = L.p2_1 / p2o;        // :813
-                }
+            if (off_resample) {
+                if (!sampled || pdf <= 0.0) alive = false; else jac = lp.p2_1() / pdf;  // :813
             }
             if (alive) { cX = c0 * jac; wgt = L.prob / (L.prob + 1.0 * jac); }      // :1019-1045
         }
         bool flagged = false;
         acc_offset(acc, k, L.contrib, cX, wgt, L.prob, spp, lc, flagged);
-        if (k == 3) { acc_base(acc, L.radiance, L.prob, spp, lc); act = ACT_NEXT_SAMPLE; }
-        else { L.k = k + 1; act = ACT_OFFSET_RAY; }
-    }
-    // ---------------- prepare the lane's next pending ray ----------------
-    if (act == ACT_BOUNCE) {                                                         // bounce iteration L.num_vertices starts at `nv`
-        lc.bounces++;
-        D2 ruv; ruv.x = pcg_real(L.rng); ruv.y = pcg_real(L.rng);                   // :536-537
-        double rw = pcg_real(L.rng);
-        if (SERIAL_RNG && L.num_vertices == 3) { L.ruv1 = ruv; L.rw1 = rw; }
-        const D3 dir_view = -ray.dir;
-        BsdfSample bs;
-        if (!mat_sample<LAMBERT>(sv, tx, nv, dir_view, ruv, rw, bs)) act = ACT_NEXT_SAMPLE;   // :545-548: GraidentPTRadiance{}
+        if (k == 3) { acc_base(acc, lp.radiance(), L.prob, spp, lc); act = ACT_NEXT_SAMPLE; }
+        else { L.kc = (L.kc & ~3) | (k + 1); act = ACT_OFFSET_RAY; }
+    } else if (act == ACT_BOUNCE) {                                                  // bounce iteration L.num_vertices starts at `nv`
+        if (!sampled) act = ACT_NEXT_SAMPLE;                                        // :545-548: GraidentPTRadiance{}
         else {
-            if (bs.eta != 0) L.eta_scale /= (bs.eta * bs.eta);                      // :553-558
-            D3 f; double pdf;
-            mat_eval_pdf<LAMBERT>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
+            // bs.eta == 0 for every one-sided lobe, so eta_scale (:553-558) stays 1 on this path
             if (pdf <= 0) {                                                         // :760-763: break before any update; the ray's
-                if (L.num_vertices == 3) { L.cmode = C_BROKE_BOUNCE1; act = ACT_OFFSETS; }           // hit is unobservable
-                else if (L.num_vertices == 4 && L.mat0 == L.mat1) { L.cmode = C_BROKE_BOUNCE2; act = ACT_OFFSETS; }   // :607-612 passed
-                else { acc_no_offsets(acc, L.radiance, L.contrib, L.prob, spp, lc); act = ACT_NEXT_SAMPLE; }
+                if (L.num_vertices == 3) { L.kc = C_BROKE_BOUNCE1 << 2; act = ACT_OFFSETS; }           // hit is unobservable
+                else if (L.num_vertices == 4 && L.mat0() == L.mat1()) { L.kc = C_BROKE_BOUNCE2 << 2; act = ACT_OFFSETS; }   // :607-612 passed
+                else { acc_no_offsets(acc, lp.radiance(), L.contrib, L.prob, spp, lc); act = ACT_NEXT_SAMPLE; }
             } else {
                 L.org = nv.position; L.dir = bs.dir_out; L.f = f; L.pdf = pdf; L.st = S_BOUNCE;
             }
         }
     }
-    if (act == ACT_OFFSETS) { L.k = 0; act = ACT_OFFSET_RAY; }
+    if (act == ACT_OFFSETS) { L.kc &= ~3; act = ACT_OFFSET_RAY; }
     if (act == ACT_NEXT_SAMPLE) {
         L.s++;
         if (L.s >= L.s_end) L.st = S_DONE; else act = ACT_PRIMARY_RAY;
@@ -362,18 +390,24 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
         double rx, ry;
         int ox = 0, oy = 0;
         if (act == ACT_PRIMARY_RAY) {
-            if (!SERIAL_RNG) L.rng = pcg_init(base + (unsigned long long)L.s);
-            rx = pcg_real(L.rng); ry = pcg_real(L.rng);                             // :360-361
+            Pcg r;
+            if (!SERIAL_RNG) r = pcg_init(base + (unsigned long long)L.s);
+            else { r.state = L.rng_state; r.inc = L.rng_inc; }
+            rx = pcg_real(r); ry = pcg_real(r);                                     // :360-361
+            L.rng_state = r.state; L.rng_inc = r.inc;
             if (SERIAL_RNG) { L.rng_x = rx; L.rng_y = ry; }
             L.st = S_PRIMARY;
         } else {
             if (SERIAL_RNG) { rx = L.rng_x; ry = L.rng_y; }
             else { Pcg r2 = pcg_init(base + (unsigned long long)L.s); rx = pcg_real(r2); ry = pcg_real(r2); }
-            const int k = L.k;
+            const int k = L.k();
             ox = (k == 0) ? -1 : (k == 1 ? 1 : 0); oy = (k == 2) ? 1 : (k == 3 ? -1 : 0);   // x0,x1,y0,y1 (:385-403)
             L.st = S_OFFSET;
         }
-        Ray r = sample_primary(cam, ((x + ox) + rx) / w, ((y + oy) + ry) / h);
+        FilterCache fc;
+        if (act == ACT_OFFSET_RAY) fc = lp.fc();
+        Ray r = sample_primary(cam, ((x + ox) + rx) / w, ((y + oy) + ry) / h, &fc, act == ACT_PRIMARY_RAY);
+        if (act == ACT_PRIMARY_RAY) lp.set_fc(fc);
         L.org = r.org; L.dir = r.dir;
     }
 }
@@ -391,7 +425,7 @@ GD unsigned long long wave_sum_u64(unsigned long long v) {
 GD void flush_counters(const KernelArgs &a, const LaneCounters &lc, const TraceCounters &tc, bool count) {
     unsigned r = wave_sum_u32(lc.rays), b = wave_sum_u32(lc.bounces), nf = wave_sum_u32(lc.nonfinite);
     unsigned long long nn = 0, np = 0;
-    if (count) { nn = wave_sum_u64(tc.nodes); np = wave_sum_u64(tc.prims); }
+    if (count) { nn = wave_sum_u64((unsigned long long)tc.nodes); np = wave_sum_u64((unsigned long long)tc.prims); }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&a.counters->rays, (unsigned long long)r);
         atomicAdd(&a.counters->bounces, (unsigned long long)b);
@@ -474,13 +508,15 @@ __global__ __launch_bounds__(kBlock, WPS) void gdpt_render_phases(DevSceneView s
     LaneCounters lc = {0, 0, 0};
     TraceCounters tc = {0, 0};
     const unsigned long long base = ((unsigned long long)(valid ? y : 0) * W + (valid ? x : 0)) * (unsigned long long)a.spp;
+    __shared__ double s_priv[kPrivDoubles * kBlock];
+    LanePriv lp; lp.slot = s_priv + tid; lp.stride = kBlock;
     Lane L;
     L.s = (int)(((long long)c * a.spp) >> a.log2k);
     L.s_end = (int)(((long long)(c + 1) * a.spp) >> a.log2k);
     L.st = (valid && L.s < L.s_end) ? S_START : S_DONE;
-    L.k = 0; L.num_vertices = 0; L.cmode = 0; L.mat0 = L.mat1 = -1;
+    L.kc = 0; L.num_vertices = 0; L.mats = 0xFFFFFF; L.rng_state = 0; L.rng_inc = 1;
     L.org = L.dir = splat(0);
-    while (__any(L.st != S_DONE)) lane_step<LAMBERT, false>(sv, tx, a.max_depth, spp, x, y, base, L, acc, lc, tc);
+    while (__any(L.st != S_DONE)) lane_step<LAMBERT, false>(sv, tx, a.max_depth, spp, x, y, base, L, lp, acc, lc, tc);
     Accum sum = acc.result();
     reduce_and_store(a, sum, K, valid && c == 0, x, y, W);
     flush_counters(a, lc, tc, a.count != 0);
@@ -491,9 +527,11 @@ __global__ __launch_bounds__(kBlock, WPS) void gdpt_render_phases(DevSceneView s
 template <bool LAMBERT>
 __global__ __launch_bounds__(64) void gdpt_render_tile_stream_phases(DevSceneView sv, KernelArgs a, int ntx, int nty) {
     __shared__ int s_stack[GDPT_BVH_MAX_DEPTH * 64];
+    __shared__ double s_priv[kPrivDoubles * 64];
     const int tid = threadIdx.x;
     const int tile = blockIdx.x * 64 + tid;
     TraceCtx tx = setup_trace<false>(sv, nullptr, s_stack, tid, 64, a.count != 0);
+    LanePriv lp; lp.slot = s_priv + tid; lp.stride = 64;
     LaneCounters lc = {0, 0, 0};
     TraceCounters tc = {0, 0};
     const int W = sv.cam.width, H = sv.cam.height;
@@ -501,8 +539,8 @@ __global__ __launch_bounds__(64) void gdpt_render_tile_stream_phases(DevSceneVie
     if (tile < ntx * nty) {
         const int txi = tile % ntx, tyi = tile / ntx;
         Lane L;
-        L.rng = pcg_init((unsigned long long)(tyi * ntx + txi));
-        L.k = 0; L.num_vertices = 0; L.cmode = 0; L.mat0 = L.mat1 = -1;
+        { Pcg r0 = pcg_init((unsigned long long)(tyi * ntx + txi)); L.rng_state = r0.state; L.rng_inc = r0.inc; }
+        L.kc = 0; L.num_vertices = 0; L.mats = 0xFFFFFF;
         L.org = L.dir = splat(0);
         const int x0 = txi * 16, x1 = min(x0 + 16, W), y0 = tyi * 16, y1 = min(y0 + 16, H);
         for (int y = y0; y < y1; y++) {
@@ -510,7 +548,7 @@ __global__ __launch_bounds__(64) void gdpt_render_tile_stream_phases(DevSceneVie
             for (int x = x0; x < x1; x++) {
                 AccReg acc; acc.init();
                 L.s = 0; L.s_end = a.spp; L.st = S_START;
-                while (L.st != S_DONE) lane_step<LAMBERT, true>(sv, tx, a.max_depth, spp, x, y, 0ull, L, acc, lc, tc);
+                while (L.st != S_DONE) lane_step<LAMBERT, true>(sv, tx, a.max_depth, spp, x, y, 0ull, L, lp, acc, lc, tc);
                 Accum sum = acc.result();
                 reduce_and_store(a, sum, 1, true, x, y, W);
             }

@@ -155,6 +155,8 @@ typedef struct GdptPoissonStats {
     double solve_ms;           /* device time, HIP events */
 } GdptPoissonStats;
 
+/* CG: conjugate gradients on W(alpha I - L) f = W h + DC shift (matches the DCT solve to the CG tolerance; differs
+ *     from the reference by its fp32-lambda quirk, ~3e-9).  DCT: direct solve, exact reference operator. */
 enum { GDPT_SOLVER_CG = 0, GDPT_SOLVER_DCT = 1 };
 
 typedef struct GdptScene GdptScene;   /* opaque: device-resident scene (BVH2, triangles, materials, textures) */
@@ -187,7 +189,9 @@ int gdpt_assemble_device(int width, int height,
                          const double *d_cx1, const double *d_cy1,
                          double *d_c, double *d_cx, double *d_cy, void *stream);
 
-/* Screened Poisson reconstruction; same arguments as fourierSolve (src/render.cpp:172-175). Host pointers. */
+/* Screened Poisson reconstruction; same arguments as fourierSolve (src/render.cpp:172-175). Host pointers.
+ * Uses GDPT_SOLVER_DCT: the reference's algorithm itself (DCT-I, fp32-rounded eigenvalue, DC override), the
+ * transform evaluated as fp64 GEMMs on the GPU. */
 int gdpt_poisson_solve(int width, int height,
                        const double *imgData, const double *imgGradX, const double *imgGradY,
                        double dataCost, double *imgOut);

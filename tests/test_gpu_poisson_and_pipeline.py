@@ -18,11 +18,23 @@ def weights(w, h):
     return wy[:, None, None] * wx[None, :, None]
 
 
+@pytest.mark.parametrize("w,h", [(8, 6), (64, 48), (2, 2), (3, 2), (33, 97), (257, 64), (512, 512), (320, 180)])
+def test_poisson_dct_gemm_matches_dct_oracle(G, O, w, h):
+    """Default solver: the reference's algorithm itself, DCT-I evaluated as fp64 GEMMs. Same operator incl. the
+    fp32-rounded eigenvalue, so it agrees with the oracle to GEMM rounding."""
+    c, gx, gy = lcg_fields(w, h, seed=w * 1000 + h)
+    ref = O.fourier_solve(c, gx, gy, 0.04)
+    out, st = G.fourierSolve(w, h, c, gx, gy, 0.04, return_stats=True)
+    assert st.solver == G.SOLVER_DCT and st.iterations == 0
+    assert rel_l2(out, ref) < 1e-11
+    np.testing.assert_allclose((weights(w, h) * out).sum(axis=(0, 1)), (weights(w, h) * c).sum(axis=(0, 1)), rtol=1e-11)
+
+
 @pytest.mark.parametrize("w,h", [(8, 6), (64, 48), (2, 2), (3, 2), (33, 97), (257, 64)])
 def test_poisson_cg_matches_dct_oracle(G, O, w, h):
     c, gx, gy = lcg_fields(w, h, seed=w * 1000 + h)
     ref = O.fourier_solve(c, gx, gy, 0.04)
-    out, st = G.fourierSolve(w, h, c, gx, gy, 0.04, return_stats=True)
+    out, st = G.fourierSolve(w, h, c, gx, gy, 0.04, solver=G.SOLVER_CG, return_stats=True)
     assert st.rel_residual < 2e-10 and st.iterations > 0
     assert rel_l2(out, ref) < 1e-6          # includes the reference's fp32-lambda quirk (3-4e-9) and the CG tolerance
     np.testing.assert_allclose((weights(w, h) * out).sum(axis=(0, 1)), (weights(w, h) * c).sum(axis=(0, 1)), rtol=1e-7)
@@ -31,6 +43,8 @@ def test_poisson_cg_matches_dct_oracle(G, O, w, h):
 def test_poisson_golden_fixture(G):
     d = np.load(os.path.join(ROOT, "tests", "golden", "poisson_64x48.npz"))
     out = G.fourierSolve(64, 48, d["c"], d["gx"], d["gy"], float(d["alpha"]))
+    assert rel_l2(out, d["out"]) < 1e-11
+    out = G.fourierSolve(64, 48, d["c"], d["gx"], d["gy"], float(d["alpha"]), solver=G.SOLVER_CG)
     assert rel_l2(out, d["out"]) < 1e-6
 
 
@@ -39,17 +53,19 @@ def test_poisson_alpha_sweep(G, O, alpha):
     # the authors swept alpha in gdpt_renders/tmp_gdpt_{0.04,0.4,4,40}.exr
     c, gx, gy = lcg_fields(40, 30, seed=int(alpha * 10))
     ref = O.fourier_solve(c, gx, gy, alpha)
-    assert rel_l2(G.fourierSolve(40, 30, c, gx, gy, alpha), ref) < 1e-6
+    assert rel_l2(G.fourierSolve(40, 30, c, gx, gy, alpha), ref) < 1e-11
+    assert rel_l2(G.fourierSolve(40, 30, c, gx, gy, alpha, solver=G.SOLVER_CG), ref) < 1e-6
 
 
 def test_poisson_linearity_and_constant_fields(G):
     w, h = 48, 40
     a = lcg_fields(w, h, seed=1)
     b = lcg_fields(w, h, seed=2)
-    fa = G.fourierSolve(w, h, *a, 0.04, tol=1e-12)
-    fb = G.fourierSolve(w, h, *b, 0.04, tol=1e-12)
-    fab = G.fourierSolve(w, h, *[2.0 * x - 0.5 * y for x, y in zip(a, b)], 0.04, tol=1e-12)
-    assert rel_l2(fab, 2.0 * fa - 0.5 * fb) < 1e-8
+    for solver, tol in ((G.SOLVER_DCT, 1e-12), (G.SOLVER_CG, 1e-8)):
+        fa = G.fourierSolve(w, h, *a, 0.04, solver=solver, tol=1e-12)
+        fb = G.fourierSolve(w, h, *b, 0.04, solver=solver, tol=1e-12)
+        fab = G.fourierSolve(w, h, *[2.0 * x - 0.5 * y for x, y in zip(a, b)], 0.04, solver=solver, tol=1e-12)
+        assert rel_l2(fab, 2.0 * fa - 0.5 * fb) < tol
     const = np.full((h, w, 3), 0.7)
     zero = np.zeros((h, w, 3))
     assert np.max(np.abs(G.fourierSolve(w, h, const, zero, zero, 0.04) - 0.7)) < 1e-9     # f = u when g = 0 = grad u
@@ -72,7 +88,7 @@ def test_full_pipeline_small(G, O, scene_tmp):
     ob, _ = O.OracleScene(sd.ptr).render(6, G.RNG_SAMPLE, threads=8)
     c, cx, cy = O.assemble(ob)
     ref = O.fourier_solve(c, cx, cy, 0.04)
-    assert rel_l2(out, ref) < 1e-6                   # north_star bar: 1e-4
+    assert rel_l2(out, ref) < 1e-9                   # north_star bar: 1e-4
     # fp32 PFM output (what the CLI writes) keeps the bar
     assert rel_l2(out.astype(np.float32), ref.astype(np.float32)) < 1e-6
 
@@ -85,12 +101,13 @@ def test_full_size_cbox_512_16spp_properties(G, O):
     sc = G.Scene(sd)
     out, bufs, rs, ps = sc.gradient_path_render(16, G.RNG_SAMPLE, return_buffers=True)
     assert rs.samples == 512 * 512 * 16 and rs.nonfinite_samples == 0
-    assert 7.0 < rs.rays / rs.samples < 9.0 and 2.5 < rs.bounces / rs.samples < 3.5     # 8.0 rays, 3.02 bounces
+    # 3.02 bounce iterations per sample; rays: 8.0 when all four offsets are always traced, ~5 with lazy offsets
+    assert 4.5 < rs.rays / rs.samples < 8.5 and 2.9 < rs.bounces / rs.samples < 3.15
     c, cx, cy = O.assemble(bufs)
     ref = O.fourier_solve(c, cx, cy, 0.04)
-    assert rel_l2(out, ref) < 1e-6
+    assert rel_l2(out, ref) < 1e-11
     wgt = weights(512, 512)
-    np.testing.assert_allclose((wgt * out).sum(axis=(0, 1)), (wgt * c).sum(axis=(0, 1)), rtol=1e-7)   # up to the CG tolerance
+    np.testing.assert_allclose((wgt * out).sum(axis=(0, 1)), (wgt * c).sum(axis=(0, 1)), rtol=1e-11)
     np.testing.assert_allclose(out.mean(axis=(0, 1)), [0.2786, 0.1124, 0.0251], rtol=0.02)     # SURVEY §6 probe / authors' cb_16.exr
     out2 = sc.gradient_path_render(16, G.RNG_SAMPLE)
     assert np.array_equal(out, out2)
