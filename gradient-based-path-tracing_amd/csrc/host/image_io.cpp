@@ -1,6 +1,8 @@
 // image_io.cpp — see image_io.h. Own writers (the reference vendors tinyexr/stb_image).
 #include "image_io.h"
 
+#include <zlib.h>
+
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -137,13 +139,40 @@ void load_texture_file(const std::string &path, int channels, int *width, int *h
     int32_t hdr[3];
     ifs.read(magic, 7);
     ifs.read((char *)hdr, 12);
-    if (!ifs || std::memcmp(magic, "GDTEX1\n", 7) != 0 || hdr[0] <= 0 || hdr[1] <= 0 || (hdr[2] != 1 && hdr[2] != 3))
+    bool v1 = std::memcmp(magic, "GDTEX1\n", 7) == 0, v2 = std::memcmp(magic, "GDTEX2\n", 7) == 0;
+    if (!ifs || !(v1 || v2) || hdr[0] <= 0 || hdr[1] <= 0 || (hdr[2] != 1 && hdr[2] != 3))
         throw std::runtime_error("Failure when loading image: bad header in " + raw);
     *width = hdr[0]; *height = hdr[1];
     int fc = hdr[2];
     std::vector<float> data((size_t)hdr[0] * hdr[1] * fc);
-    ifs.read((char *)data.data(), (std::streamsize)(data.size() * sizeof(float)));
-    if (!ifs) throw std::runtime_error("Failure when loading image: truncated " + raw);
+    if (v1) {
+        ifs.read((char *)data.data(), (std::streamsize)(data.size() * sizeof(float)));
+        if (!ifs) throw std::runtime_error("Failure when loading image: truncated " + raw);
+    } else {
+        // 8-bit texels, zlib-compressed; widened like stbi_loadf: (float)pow(v/255.0f, 2.2f) (stb_image.h:1849).
+        // A 1-channel request is reduced in 8 bits first, as stb does: y = (77 r + 150 g + 29 b) >> 8 (stb_image.h:1708).
+        uint32_t zlen = 0;
+        ifs.read((char *)&zlen, 4);
+        std::vector<unsigned char> z(zlen), u8((size_t)hdr[0] * hdr[1] * fc);
+        ifs.read((char *)z.data(), zlen);
+        if (!ifs) throw std::runtime_error("Failure when loading image: truncated " + raw);
+        uLongf out_len = (uLongf)u8.size();
+        if (uncompress(u8.data(), &out_len, z.data(), zlen) != Z_OK || out_len != u8.size())
+            throw std::runtime_error("Failure when loading image: corrupt " + raw);
+        float lut[256];
+        for (int v = 0; v < 256; v++) lut[v] = (float)(std::pow((double)(v / 255.0f), (double)2.2f) * (double)1.0f);
+        size_t npx = (size_t)hdr[0] * hdr[1];
+        if (channels == 1 && fc == 3) {
+            data.resize(npx);
+            for (size_t i = 0; i < npx; i++) {
+                int y = (u8[3 * i] * 77 + u8[3 * i + 1] * 150 + 29 * u8[3 * i + 2]) >> 8;
+                data[i] = lut[y & 255];
+            }
+            fc = 1;
+        } else {
+            for (size_t i = 0; i < u8.size(); i++) data[i] = lut[u8[i]];
+        }
+    }
     size_t n = (size_t)hdr[0] * hdr[1];
     texels->resize(n * channels);
     for (size_t i = 0; i < n; i++) {

@@ -103,6 +103,29 @@ def test_disney_lobes_gradpath(G, O, scene_tmp, scene):
         assert rel_l2(got[k], want[k]) < 1e-7, k
 
 
+def test_sponza_textures_sphere_light_big_bvh(G, O, scene_tmp):
+    """BASELINE config 4 geometry: 66 445 triangles in 37 meshes with vertex normals + 1 sphere light, 10 image
+    textures (mip levels at the primary vertex), BVH walked from HBM. Textures are the pre-decoded .gdtex companions."""
+    xml = scene_variant(scene_tmp, "sponza/sponza.xml", width=96, height=72)
+    sd = G.parse_scene(xml)
+    sc = G.Scene(sd)
+    info = sc.info()
+    assert info["num_tris"] == 66445 and info["num_spheres"] == 1 and info["bvh_depth"] <= 32
+    got, st = sc.render(4, G.RNG_SAMPLE)
+    want, ost = O.OracleScene(sd.ptr, use_bvh=True).render(4, G.RNG_SAMPLE, threads=8)
+    assert st.bounces == ost.bounces and st.nonfinite_samples == ost.nonfinite_samples
+    for k in BUFS[1:]:
+        assert np.abs(want[k]).max() > 0
+    for k in BUFS:
+        err = rel_l2(got[k], want[k])
+        assert err < 1e-7, (k, err)
+    tile, st2 = sc.render(2, G.RNG_TILE)
+    wtile, ost2 = O.OracleScene(sd.ptr, use_bvh=True).render(2, G.RNG_TILE, threads=8)
+    assert st2.bounces == ost2.bounces
+    for k in BUFS:
+        assert rel_l2(tile[k], wtile[k]) < 1e-7, k
+
+
 def test_textured_two_sided_synthetic_scene(G, O):
     """Image texture with mip levels on the primary vertex, checkerboard, glass (two-sided: offsets survive past the
     first bounce under A-semantics), an emitter — built directly as a GdptSceneDesc."""
