@@ -133,6 +133,16 @@ def main():
     alg_bytes = cs.rays * 64 + cs.nodes_visited * 64 + cs.tris_tested * 48 + cs.bounces * 320
     achieved = alg_bytes / (render_ms_avg * 1e-3) / 1e9 if render_ms_avg > 0 else 0.0
 
+    # HBM bytes of the render kernel from the PMC passes committed under profiles/ (same command, same workload);
+    # bench.py cannot run rocprofv3 around itself
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_b_hbm_traffic.json")
+    if world == 1 and args.spp == 16 and os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath))["render_traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
+
     samples_rank = W * (r1 - r0) * spp_total
     samples_all = W * H * spp_total
     ms_per_step = elapsed / args.steps * 1e3
@@ -150,8 +160,8 @@ def main():
         "render_ms": render_ms_avg, "render_msamples_per_s": samples_rank / render_ms_avg / 1e3 if render_ms_avg > 0 else 0.0,
         "poisson_ms": poisson_ms_avg, "poisson_iterations": iters,
         "rays_per_sample": cs.rays / max(1, cs.samples), "bounces_per_sample": cs.bounces / max(1, cs.samples),
-        "roofline": {"bound": "hbm", "kernel": "gdpt_render_sample_stream", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "roofline": {"bound": "hbm", "kernel": "gdpt_render_phases", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": render_ms_avg,
                      "nodes_per_ray": cs.nodes_visited / max(1, cs.rays), "prims_per_ray": cs.tris_tested / max(1, cs.rays)},
     }
