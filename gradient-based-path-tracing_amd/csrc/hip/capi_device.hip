@@ -48,6 +48,9 @@ struct GdptScene {
     size_t buf_elems = 0;
     gdpt::RenderCounters *d_counters = nullptr;
     gdpt::RenderCounters *h_counters = nullptr; // pinned
+    double *d_partials = nullptr; size_t partials_doubles = 0;   // work-item partial sums of the persistent render kernel
+    unsigned long long *d_queue = nullptr;
+    int num_cus = 256;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     template <class T>
@@ -64,6 +67,8 @@ struct GdptScene {
         for (void *p : allocations) hipFree(p);
         for (auto &b : d_buf) if (b) hipFree(b);
         if (d_counters) hipFree(d_counters);
+        if (d_partials) hipFree(d_partials);
+        if (d_queue) hipFree(d_queue);
         if (h_counters) hipHostFree(h_counters);
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
@@ -243,6 +248,8 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     v.isect_eps = std::min(radius * 1e-5, 0.01);
 
     ck(hipMalloc((void **)&sc->d_counters, sizeof(gdpt::RenderCounters)), "hipMalloc(counters)");
+    ck(hipMalloc((void **)&sc->d_queue, sizeof(unsigned long long)), "hipMalloc(queue)");
+    { hipDeviceProp_t prop; ck(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties"); sc->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
     ck(hipHostMalloc((void **)&sc->h_counters, sizeof(gdpt::RenderCounters)), "hipHostMalloc(counters)");
     ck(hipEventCreate(&sc->ev0), "hipEventCreate");
     ck(hipEventCreate(&sc->ev1), "hipEventCreate");
@@ -287,6 +294,16 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.thresh_a = env_int("GDPT_THRESH_A", 0); rl.thresh_c = env_int("GDPT_THRESH_C", 0);
     rl.force_log2k = env_int("GDPT_LOG2K", -1);
     rl.waves_per_simd = env_int("GDPT_WPS", 2);
+    rl.num_cus = sc->num_cus;
+    {
+        size_t need = gdpt::render_partials_doubles((long long)sc->view.cam.width * (b.row_end - b.row_begin), b.spp);
+        if (need > sc->partials_doubles) {
+            if (sc->d_partials) { ck(hipStreamSynchronize(stream), "hipStreamSynchronize"); hipFree(sc->d_partials); sc->d_partials = nullptr; }
+            ck(hipMalloc((void **)&sc->d_partials, need * sizeof(double)), "hipMalloc(work-item partials)");
+            sc->partials_doubles = need;
+        }
+        rl.partials = sc->d_partials; rl.queue_head = sc->d_queue;
+    }
     if (env_int("GDPT_NO_LDS_SCENE", 0)) rl.scene_fits_lds = false;
     ck(hipMemsetAsync(sc->d_counters, 0, sizeof(gdpt::RenderCounters), stream), "hipMemsetAsync(counters)");
     if (stats) ck(hipEventRecord(sc->ev0, stream), "hipEventRecord");

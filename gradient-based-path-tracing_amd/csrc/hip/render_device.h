@@ -47,7 +47,10 @@ struct KernelArgs {
     int spp, log2k, tile_w, tile_h, tiles_x;
     int row_begin, row_end, max_depth;
     int thresh_a, thresh_c;
-    int count, pad_;
+    int count, chunks;                 // chunks: work items per pixel
+    long long num_items;               // pixels in the band * chunks
+    double *partials;                  // [15][num_items]
+    unsigned long long *queue_head;    // work-queue head (zeroed per launch)
     double *img, *cx0, *cy0, *cx1, *cy1;
     gdpt::RenderCounters *counters;
 };
@@ -485,42 +488,127 @@ GD TraceCtx setup_trace(const DevSceneView &sv, unsigned char *s_scene, int *s_s
     return tx;
 }
 
-// SAMPLE stream: init_pcg32((y*W+x)*spp + s) per sample; K = 2^log2k lanes share a pixel, each owns a chunk of
-// its samples. WPS = waves per SIMD the register allocator must leave room for.
+// Work items of the persistent kernel: item = pixel_index * C + chunk, pixels enumerated tile by tile (16x16, the
+// reference's tile shape) inside the band so that a wave's batch of 64 consecutive items covers neighbouring pixels.
+GD void item_to_pixel(const KernelArgs &a, int W, long long item, int &x, int &y, int &s0, int &s1) {
+    const int C = a.chunks;
+    const long long p = item / C;
+    const int c = (int)(item - p * C);
+    const int tiles_x = (W + 15) >> 4;
+    const int rows = a.row_end - a.row_begin;
+    // pixels of full tile rows: 16 * W each (ragged right tiles are narrower, so walk tile rows explicitly)
+    const long long per_tile_row = (long long)16 * W;
+    const int trow = (int)(p / per_tile_row);
+    long long q = p - (long long)trow * per_tile_row;
+    const int th = min(16, rows - trow * 16);          // height of this tile row (last one may be short)
+    // inside a tile row: tiles left to right, each tile th x tw pixels in row-major order
+    const long long full_tile = (long long)16 * th;
+    int tcol = (int)(q / full_tile);
+    if (tcol >= tiles_x) tcol = tiles_x - 1;
+    q -= (long long)tcol * full_tile;
+    const int tw = min(16, W - tcol * 16);
+    const int py = (int)(q / tw), px = (int)(q - (long long)py * tw);
+    x = tcol * 16 + px; y = a.row_begin + trow * 16 + py;
+    s0 = (int)(((long long)c * a.spp) / C); s1 = (int)(((long long)(c + 1) * a.spp) / C);
+}
+
+// SAMPLE stream, persistent threads. Every lane repeatedly takes a work item (pixel, chunk of the pixel's samples)
+// from a global queue — fetched 64 at a time per wave with one atomicAdd — and runs the lane machine on it; a lane
+// that finishes early picks up the next item instead of idling behind the longest path of its wave. Per-item sums go
+// to `partials` ([15][items], one writer per slot) and are merged per pixel in chunk order by gdpt_reduce_partials,
+// so the result does not depend on which lane processed what, or when.
 template <bool LAMBERT, bool LDS_SCENE, int WPS>
 __global__ __launch_bounds__(kBlock, WPS) void gdpt_render_phases(DevSceneView sv, KernelArgs a) {
     constexpr int kLevels = LDS_SCENE ? kLdsSceneLevels : GDPT_BVH_MAX_DEPTH;
     __shared__ int s_stack[kLevels * kBlock];
     __shared__ __attribute__((aligned(16))) unsigned char s_scene[LDS_SCENE ? kLdsSceneBytes : 16];
+    __shared__ double s_acc[15 * kBlock];
+    __shared__ double s_priv[kPrivDoubles * kBlock];
     const int tid = threadIdx.x;
     TraceCtx tx = setup_trace<LDS_SCENE>(sv, s_scene, s_stack, tid, kBlock, a.count != 0);
-    const int K = 1 << a.log2k;
-    const int c = tid & (K - 1), p = tid >> a.log2k;
-    const int px = p % a.tile_w, py = p / a.tile_w;
-    const int bx = blockIdx.x % a.tiles_x, by = blockIdx.x / a.tiles_x;
-    const int x = bx * a.tile_w + px, y = a.row_begin + by * a.tile_h + py;
     const int W = sv.cam.width;
-    const bool valid = (x < W) && (y < a.row_end);
     const double spp = (double)a.spp;
-    __shared__ double s_acc[15 * kBlock];
     AccLds acc; acc.slot = s_acc + tid; acc.stride = kBlock;
     acc.init();
+    LanePriv lp; lp.slot = s_priv + tid; lp.stride = kBlock;
     LaneCounters lc = {0, 0, 0};
     TraceCounters tc = {0, 0};
-    const unsigned long long base = ((unsigned long long)(valid ? y : 0) * W + (valid ? x : 0)) * (unsigned long long)a.spp;
-    __shared__ double s_priv[kPrivDoubles * kBlock];
-    LanePriv lp; lp.slot = s_priv + tid; lp.stride = kBlock;
     Lane L;
-    L.s = (int)(((long long)c * a.spp) >> a.log2k);
-    L.s_end = (int)(((long long)(c + 1) * a.spp) >> a.log2k);
-    L.st = (valid && L.s < L.s_end) ? S_START : S_DONE;
+    L.s = 0; L.s_end = 0; L.st = S_DONE;
     L.kc = 0; L.num_vertices = 0; L.mats = 0xFFFFFF; L.rng_state = 0; L.rng_inc = 1;
     L.org = L.dir = splat(0);
-    while (__any(L.st != S_DONE)) lane_step<LAMBERT, false>(sv, tx, a.max_depth, spp, x, y, base, L, lp, acc, lc, tc);
-    Accum sum = acc.result();
-    reduce_and_store(a, sum, K, valid && c == 0, x, y, W);
+    int x = 0, y = 0;
+    unsigned long long base = 0;
+    long long my_item = -1;
+    // wave-local slice of the queue (uniform across the wave)
+    long long q_next = 0, q_end = 0;
+    bool exhausted = false;
+    const unsigned long long lane_lt = (1ull << (tid & 63)) - 1ull;
+    for (;;) {
+        // ---- hand out work to idle lanes
+        const bool idle = (L.st == S_DONE);
+        if (idle && my_item >= 0) {                     // item finished: publish its 15 sums, clear the slot
+            Accum r = acc.result();
+            double *dst = a.partials + my_item;
+            const long long n = a.num_items;
+            dst[0] = r.r.x; dst[n] = r.r.y; dst[2 * n] = r.r.z;
+            dst[3 * n] = r.dx0.x; dst[4 * n] = r.dx0.y; dst[5 * n] = r.dx0.z;
+            dst[6 * n] = r.dy0.x; dst[7 * n] = r.dy0.y; dst[8 * n] = r.dy0.z;
+            dst[9 * n] = r.dx1.x; dst[10 * n] = r.dx1.y; dst[11 * n] = r.dx1.z;
+            dst[12 * n] = r.dy1.x; dst[13 * n] = r.dy1.y; dst[14 * n] = r.dy1.z;
+            acc.init();
+            my_item = -1;
+        }
+        const unsigned long long m_idle = __ballot(idle);
+        if (m_idle) {
+            if (q_next >= q_end && !exhausted) {        // refill the wave's slice: one atomic per 64 items
+                unsigned long long got = 0;
+                if ((tid & 63) == 0) got = atomicAdd(a.queue_head, 64ull);
+                got = __shfl(got, 0, 64);
+                q_next = (long long)got;
+                q_end = min((long long)got + 64, a.num_items);
+                if (q_next >= a.num_items) { exhausted = true; q_end = q_next; }
+            }
+            const int avail = (int)(q_end - q_next);
+            const int rank = __popcll(m_idle & lane_lt);
+            if (idle && rank < avail) {
+                my_item = q_next + rank;
+                int s0, s1;
+                item_to_pixel(a, W, my_item, x, y, s0, s1);
+                base = ((unsigned long long)y * W + x) * (unsigned long long)a.spp;
+                L.s = s0; L.s_end = s1;
+                L.st = (s0 < s1) ? S_START : S_DONE;
+            }
+            const int n_idle = __popcll(m_idle);
+            q_next += (n_idle < avail) ? n_idle : avail;
+        }
+        if (!__any(L.st != S_DONE)) { if (exhausted) break; else continue; }
+        lane_step<LAMBERT, false>(sv, tx, a.max_depth, spp, x, y, base, L, lp, acc, lc, tc);
+    }
     flush_counters(a, lc, tc, a.count != 0);
 }
+
+#ifdef GDPT_BUILD_REDUCE   // emitted by render_phases_lambert.hip only (non-template kernel)
+// Sums the C per-chunk partials of every pixel in chunk order and writes the five images (one thread per pixel).
+__global__ __launch_bounds__(256) void gdpt_reduce_partials(KernelArgs a, int W) {
+    const long long npix = a.num_items / a.chunks;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // pixel index in item order
+    if (idx >= npix) return;
+    int x, y, s0, s1;
+    item_to_pixel(a, W, idx * a.chunks, x, y, s0, s1);
+    const size_t o = ((size_t)y * W + x) * 3;
+    double *img[5] = {a.img, a.cx0, a.cy0, a.cx1, a.cy1};
+#pragma unroll
+    for (int b = 0; b < 5; b++)
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const double *src = a.partials + (size_t)(b * 3 + ch) * a.num_items + idx * a.chunks;
+            double v = 0;
+            for (int c = 0; c < a.chunks; c++) v += src[c];
+            img[b][o + ch] = v;
+        }
+}
+#endif // GDPT_BUILD_REDUCE
 
 // TILE stream: bit-for-bit the reference's RNG order — one PCG stream per 16x16 tile, pixels y-outer / x-inner,
 // samples innermost (src/render.cpp:281-309). Serial per tile => one lane per tile. For checks.
@@ -735,6 +823,7 @@ __global__ __launch_bounds__(64) void gdpt_render_tile_stream_eager(DevSceneView
 namespace gdpt {
 // host launchers, one translation unit per kernel family (parallel compilation)
 void launch_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, int wps, hipStream_t stream);
+void launch_reduce_partials(const DevSceneView &sv, const gd::KernelArgs &a, hipStream_t stream);
 void launch_phases_general(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, hipStream_t stream);
 void launch_tile_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
 void launch_tile_phases_general(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);

@@ -25,8 +25,14 @@ struct RenderLaunch {
     int thresh_a, thresh_c;        // lanes that must wait for phase A / C before a wave runs it (0 = default)
     int force_log2k;               // lanes per pixel = 2^force_log2k (-1 = automatic)
     int waves_per_simd;            // register budget variant of the phase kernel (2, 3 or 4)
+    int num_cus;                   // compute units of the device (persistent grid size)
+    double *partials;              // device, >= 15 * W * rows * 8 doubles (work-item partial sums)
+    unsigned long long *queue_head;// device, work-queue head
 };
 bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_materials, int bvh_depth);
+
+// Doubles the `partials` buffer must hold for a band of `pixels` pixels at `spp`.
+size_t render_partials_doubles(long long pixels, int spp);
 
 // Enqueues the five-buffer render on `stream`. Throws std::runtime_error on a launch failure.
 void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t stream);

@@ -27,26 +27,51 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
         else if (rl.lambert_only) launch_tile_phases_lambert(sv, a, grid, ntx, nty, stream);
         else launch_tile_phases_general(sv, a, grid, ntx, nty, stream);
     } else if (rl.rng_scheme == GDPT_RNG_SAMPLE) {
-        // lanes per pixel: enough lanes to fill the chip but never more than spp
-        long long pixels = (long long)W * rows;
-        int log2k = 0;
-        while ((1 << (log2k + 1)) <= rl.spp && log2k < 6 && (pixels << log2k) < (1LL << 19)) log2k++;
-        if (rl.force_log2k >= 0) { log2k = rl.force_log2k; while (log2k > 0 && (1 << log2k) > rl.spp) log2k--; }
-        a.log2k = log2k;
-        int ppb = gd::kBlock >> log2k;                 // pixels per block
-        a.tile_w = ppb >= 16 ? 16 : ppb;
-        a.tile_h = ppb / a.tile_w;
-        a.tiles_x = (W + a.tile_w - 1) / a.tile_w;
-        int tiles_y = (rows + a.tile_h - 1) / a.tile_h;
-        dim3 grid((unsigned)(a.tiles_x * tiles_y));
-        if (!phases) launch_eager(sv, a, grid, stream);
-        else if (rl.lambert_only) launch_phases_lambert(sv, a, grid, rl.scene_fits_lds, rl.waves_per_simd, stream);
-        else launch_phases_general(sv, a, grid, rl.scene_fits_lds, stream);
+        if (!phases) {
+            // eager evaluator: static mapping, K = 2^log2k lanes per pixel
+            long long pixels = (long long)W * rows;
+            int log2k = 0;
+            while ((1 << (log2k + 1)) <= rl.spp && log2k < 6 && (pixels << log2k) < (1LL << 19)) log2k++;
+            if (rl.force_log2k >= 0) { log2k = rl.force_log2k; while (log2k > 0 && (1 << log2k) > rl.spp) log2k--; }
+            a.log2k = log2k;
+            int ppb = gd::kBlock >> log2k;                 // pixels per block
+            a.tile_w = ppb >= 16 ? 16 : ppb;
+            a.tile_h = ppb / a.tile_w;
+            a.tiles_x = (W + a.tile_w - 1) / a.tile_w;
+            int tiles_y = (rows + a.tile_h - 1) / a.tile_h;
+            launch_eager(sv, a, dim3((unsigned)(a.tiles_x * tiles_y)), stream);
+        } else {
+            // persistent lanes pulling (pixel, chunk) items: ~4 samples per item, at most 8 items per pixel
+            int chunks = rl.spp / 4;
+            chunks = chunks < 1 ? 1 : (chunks > 8 ? 8 : chunks);
+            if (rl.force_log2k >= 0) { chunks = 1 << rl.force_log2k; if (chunks > rl.spp) chunks = rl.spp; }
+            a.chunks = chunks;
+            a.num_items = (long long)W * rows * chunks;
+            a.partials = rl.partials; a.queue_head = rl.queue_head;
+            if (!a.partials || !a.queue_head) throw std::runtime_error("launch_render: work-queue buffers missing");
+            hipError_t me = hipMemsetAsync(a.queue_head, 0, sizeof(unsigned long long), stream);
+            if (me != hipSuccess) throw std::runtime_error("launch_render: queue reset failed");
+            long long waves_needed = (a.num_items + 63) / 64;
+            long long blocks = (long long)rl.num_cus * 2;              // 2 resident blocks per CU (LDS-bound); surplus blocks just queue
+            if (blocks > (waves_needed + 3) / 4) blocks = (waves_needed + 3) / 4;
+            if (blocks < 1) blocks = 1;
+            dim3 grid((unsigned)blocks);
+            if (rl.lambert_only) launch_phases_lambert(sv, a, grid, rl.scene_fits_lds, rl.waves_per_simd, stream);
+            else launch_phases_general(sv, a, grid, rl.scene_fits_lds, stream);
+            launch_reduce_partials(sv, a, stream);
+        }
     } else {
         throw std::runtime_error("launch_render: unknown rng_scheme");
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) throw std::runtime_error(std::string("render kernel launch failed: ") + hipGetErrorString(e));
+}
+
+size_t render_partials_doubles(long long pixels, int spp) {
+    int chunks = spp / 4;
+    chunks = chunks < 1 ? 1 : (chunks > 8 ? 8 : chunks);
+    if (chunks < 8) chunks = 8;   // room for the GDPT_LOG2K override
+    return (size_t)15 * (size_t)pixels * (size_t)chunks;
 }
 
 bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_materials, int bvh_depth) {

@@ -1,4 +1,5 @@
 // Lambertian-only scenes (cbox, sponza): phase-machine kernels with the cosine lobe inlined.
+#define GDPT_BUILD_REDUCE 1
 #include "render_device.h"
 namespace gdpt {
 template <int WPS>
@@ -10,6 +11,10 @@ void launch_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3
     if (wps >= 4) launch_wps<4>(sv, a, grid, lds, stream);
     else if (wps == 3) launch_wps<3>(sv, a, grid, lds, stream);
     else launch_wps<2>(sv, a, grid, lds, stream);
+}
+void launch_reduce_partials(const DevSceneView &sv, const gd::KernelArgs &a, hipStream_t stream) {
+    const long long npix = a.num_items / a.chunks;
+    hipLaunchKernelGGL(gd::gdpt_reduce_partials, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, a, sv.cam.width);
 }
 void launch_tile_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream) {
     hipLaunchKernelGGL((gd::gdpt_render_tile_stream_phases<true>), grid, dim3(64), 0, stream, sv, a, ntx, nty);
