@@ -92,58 +92,18 @@ GD void test_prim(const DevSceneView &sv, const DevPrim &pr, const float o[3], c
 }
 
 // Slab test against boxes the host has already widened (gdpt_scene_upload pads every child box by 1e-6 of the scene
-// extent, which dominates the rounding of (bound - origin)); the remaining relative error of the products is
+// extent). Distances are formed as fma(bound, 1/d, -o/d): the cancellation error of that form is at most
+// 2^-24 |o| |1/d|, an eighth of the padding's 1e-6 extent |1/d|; the remaining relative error of the products is
 // absorbed by the 1e-6 slack on the exit distance. Never rejects a box holding a primitive that can report t <= tbest.
-GD bool box_hit(const float *mn, const float *mx, const float o[3], const float inv[3], float tnear, float tbest, float &tin) {
+GD bool box_hit(const float *mn, const float *mx, const float oi[3], const float inv[3], float tnear, float tbest, float &tin) {
     float t0 = tnear, t1 = tbest;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        float a = (mn[k] - o[k]) * inv[k], b = (mx[k] - o[k]) * inv[k];
-        t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));       // NaN (0*inf on flat boxes) is dropped by fmin/fmax
+        float a = fmaf(mn[k], inv[k], -oi[k]), b = fmaf(mx[k], inv[k], -oi[k]);
+        t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));       // NaN (inf - inf, 0*inf) is dropped by fmin/fmax
     }
     tin = t0;
     return t0 <= t1 * 1.000001f;
-}
-
-// `stack` points at this lane's slot 0 in LDS; consecutive levels are `stride` ints apart
-// (stride = block size, so a wave's accesses to one level hit 64 consecutive banks).
-template <bool COUNT>
-GD Hit closest_hit(const DevSceneView &sv, const float o[3], const float d[3], float tnear, float tfar,
-                   int *stack, int stride, TraceCounters &tc) {
-    Hit best; best.gid = -1; best.t = tfar; best.u = best.v = 0; best.ngx = best.ngy = best.ngz = 0;
-    if (sv.num_nodes == 0) return best;
-    float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
-    int sp = 0;
-    int cur = 0;
-    for (;;) {
-        if (cur >= 0) {
-            const DevBvhNode &n = sv.nodes[cur];
-            if (COUNT) tc.nodes++;
-            float tb = best.t;   // == tfar until something is hit (t < tfar, so <= is safe)
-            float tl, tr;
-            bool hl = (n.left != GDPT_CHILD_EMPTY) && box_hit(n.lmin, n.lmax, o, inv, tnear, tb, tl);
-            bool hr = (n.right != GDPT_CHILD_EMPTY) && box_hit(n.rmin, n.rmax, o, inv, tnear, tb, tr);
-            if (hl && hr) {
-                int nearc = n.left, farc = n.right;
-                if (tr < tl) { nearc = n.right; farc = n.left; }
-                stack[sp * stride] = farc; sp++;
-                cur = nearc;
-                continue;
-            } else if (hl) { cur = n.left; continue; }
-            else if (hr) { cur = n.right; continue; }
-        } else {
-            unsigned packed = ~(unsigned)cur;
-            unsigned first = packed >> 2, cnt = (packed & 3u) + 1u;
-            for (unsigned i = 0; i < cnt; i++) {
-                if (COUNT) tc.prims++;
-                test_prim(sv, sv.prims[first + i], o, d, tnear, tfar, best);
-            }
-        }
-        if (sp == 0) break;
-        sp--;
-        cur = stack[sp * stride];
-    }
-    return best;
 }
 
 // ---- intersect() post-processing: src/intersection.cpp:37-63 + compute_shading_info ----------------

@@ -139,14 +139,20 @@ GD Hit closest_hit_ctx(const DevSceneView &sv, const TraceCtx &tx, const float o
     Hit best; best.gid = -1; best.t = tfar; best.u = best.v = 0; best.ngx = best.ngy = best.ngz = 0;
     if (sv.num_nodes == 0) return best;
     float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+    float oi[3] = {o[0] * inv[0], o[1] * inv[1], o[2] * inv[2]};
+    // a zero direction component gives inv = inf and o*inv = inf or NaN: the slab then drops out of fmin/fmax only if
+    // the product is NaN, so force it (the ray is parallel to that slab; the padded box contains the origin's
+    // coordinate or the other axes reject)
+#pragma unroll
+    for (int k = 0; k < 3; k++) if (d[k] == 0.0f) { inv[k] = __builtin_nanf(""); oi[k] = __builtin_nanf(""); }
     int sp = 0, cur = 0;
     for (;;) {
         if (cur >= 0) {
             const DevBvhNode &n = tx.nodes[cur];
             if (tx.count) tc.nodes++;
             float tb = best.t, tl, tr;
-            bool hl = (n.left != GDPT_CHILD_EMPTY) && box_hit(n.lmin, n.lmax, o, inv, tnear, tb, tl);
-            bool hr = (n.right != GDPT_CHILD_EMPTY) && box_hit(n.rmin, n.rmax, o, inv, tnear, tb, tr);
+            bool hl = (n.left != GDPT_CHILD_EMPTY) && box_hit(n.lmin, n.lmax, oi, inv, tnear, tb, tl);
+            bool hr = (n.right != GDPT_CHILD_EMPTY) && box_hit(n.rmin, n.rmax, oi, inv, tnear, tb, tr);
             if (hl && hr) {
                 int nearc = n.left, farc = n.right;
                 if (tr < tl) { nearc = n.right; farc = n.left; }

@@ -48,6 +48,23 @@ def test_cbox_tile_stream_reference_rng_order(G, O, scene_tmp):
     assert st.bounces == ost.bounces
 
 
+def test_work_item_granularity_does_not_change_the_result(G, scene_tmp, monkeypatch):
+    """The persistent kernel cuts a pixel's samples into work items whose partial sums are merged in chunk order;
+    1, 2 or 8 items per pixel (and the eager evaluator) must agree to summation-order rounding."""
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=40, height=24)
+    sc = G.Scene(G.parse_scene(xml))
+    ref, rst = sc.render(16, G.RNG_SAMPLE)
+    for env in ({"GDPT_LOG2K": "0"}, {"GDPT_LOG2K": "1"}, {"GDPT_LOG2K": "3"}, {"GDPT_FORCE_EAGER": "1"}, {"GDPT_NO_LDS_SCENE": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got, st = sc.render(16, G.RNG_SAMPLE)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert st.bounces == rst.bounces
+        for k in BUFS:
+            assert rel_l2(got[k], ref[k]) < 1e-12, (env, k)
+
+
 def test_row_bands_compose_to_the_whole_image(G, scene_tmp):
     xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=40, height=64)
     sd = G.parse_scene(xml)
