@@ -295,6 +295,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.force_log2k = env_int("GDPT_LOG2K", -1);
     rl.waves_per_simd = env_int("GDPT_WPS", 2);
     rl.num_cus = sc->num_cus;
+    rl.blocks_per_cu = env_int("GDPT_BLOCKS_PER_CU", 0);
     {
         size_t need = gdpt::render_partials_doubles((long long)sc->view.cam.width * (b.row_end - b.row_begin), b.spp);
         if (need > sc->partials_doubles) {

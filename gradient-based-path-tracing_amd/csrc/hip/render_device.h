@@ -135,6 +135,9 @@ struct TraceCtx {
     bool need_uv;     // wave-uniform: some texture is not constant (uv / footprint are observable)
 };
 
+// WW: "while-while" loop order (large scenes walked from HBM: +6 % on sponza) vs. one node or leaf per trip (scenes
+// resident in LDS: +5 % on cbox).
+template <bool WW>
 GD Hit closest_hit_ctx(const DevSceneView &sv, const TraceCtx &tx, const float o[3], const float d[3], float tnear, float tfar, TraceCounters &tc) {
     Hit best; best.gid = -1; best.t = tfar; best.u = best.v = 0; best.ngx = best.ngy = best.ngz = 0;
     if (sv.num_nodes == 0) return best;
@@ -145,9 +148,44 @@ GD Hit closest_hit_ctx(const DevSceneView &sv, const TraceCtx &tx, const float o
     // coordinate or the other axes reject)
 #pragma unroll
     for (int k = 0; k < 3; k++) if (d[k] == 0.0f) { inv[k] = __builtin_nanf(""); oi[k] = __builtin_nanf(""); }
+    if (!WW) {
+        int sp = 0, cur = 0;
+        for (;;) {
+            if (cur >= 0) {
+                const DevBvhNode &n = tx.nodes[cur];
+                if (tx.count) tc.nodes++;
+                float tb = best.t, tl, tr;
+                bool hl = (n.left != GDPT_CHILD_EMPTY) && box_hit(n.lmin, n.lmax, oi, inv, tnear, tb, tl);
+                bool hr = (n.right != GDPT_CHILD_EMPTY) && box_hit(n.rmin, n.rmax, oi, inv, tnear, tb, tr);
+                if (hl && hr) {
+                    int nearc = n.left, farc = n.right;
+                    if (tr < tl) { nearc = n.right; farc = n.left; }
+                    tx.stack[sp * tx.stride] = farc; sp++;
+                    cur = nearc;
+                    continue;
+                } else if (hl) { cur = n.left; continue; }
+                else if (hr) { cur = n.right; continue; }
+            } else {
+                unsigned packed = ~(unsigned)cur;
+                unsigned first = packed >> 2, cnt = (packed & 3u) + 1u;
+#pragma unroll 1
+                for (unsigned i = 0; i < cnt; i++) {
+                    if (tx.count) tc.prims++;
+                    test_prim(sv, tx.prims[first + i], o, d, tnear, tfar, best);
+                }
+            }
+            if (sp == 0) break;
+            sp--;
+            cur = tx.stack[sp * tx.stride];
+        }
+        return best;
+    }
+    // "while-while" traversal: all lanes first walk inner nodes until each holds a leaf (or has finished), then the
+    // leaves are intersected together — keeps the box-test code and the triangle-test code from serialising each other.
     int sp = 0, cur = 0;
+    bool done = false;
     for (;;) {
-        if (cur >= 0) {
+        while (cur >= 0 && !done) {
             const DevBvhNode &n = tx.nodes[cur];
             if (tx.count) tc.nodes++;
             float tb = best.t, tl, tr;
@@ -158,10 +196,13 @@ GD Hit closest_hit_ctx(const DevSceneView &sv, const TraceCtx &tx, const float o
                 if (tr < tl) { nearc = n.right; farc = n.left; }
                 tx.stack[sp * tx.stride] = farc; sp++;
                 cur = nearc;
-                continue;
-            } else if (hl) { cur = n.left; continue; }
-            else if (hr) { cur = n.right; continue; }
-        } else {
+            } else if (hl) cur = n.left;
+            else if (hr) cur = n.right;
+            else if (sp > 0) { sp--; cur = tx.stack[sp * tx.stride]; }
+            else done = true;
+        }
+        if (done) break;
+        {
             unsigned packed = ~(unsigned)cur;
             unsigned first = packed >> 2, cnt = (packed & 3u) + 1u;
 #pragma unroll 1
@@ -177,11 +218,12 @@ GD Hit closest_hit_ctx(const DevSceneView &sv, const TraceCtx &tx, const float o
     return best;
 }
 
+template <bool WW>
 GD bool intersect_ctx(const DevSceneView &sv, const TraceCtx &tx, const Ray &ray, double rd_spread, Vertex &v, LaneCounters &lc, TraceCounters &tc) {
     float o[3] = {(float)ray.org.x, (float)ray.org.y, (float)ray.org.z};
     float d[3] = {(float)ray.dir.x, (float)ray.dir.y, (float)ray.dir.z};
     lc.rays++;
-    Hit h = closest_hit_ctx(sv, tx, o, d, (float)ray.tnear, (float)ray.tfar, tc);
+    Hit h = closest_hit_ctx<WW>(sv, tx, o, d, (float)ray.tnear, (float)ray.tfar, tc);
     if (h.gid < 0) return false;
     make_vertex(sv, tx.tris, tx.need_uv, ray, h, 0.0, rd_spread, v);
     return true;
@@ -268,7 +310,7 @@ struct Lane {
 
 // SERIAL_RNG: one PCG stream runs through consecutive samples (TILE scheme); otherwise each sample owns stream
 // `base + s` (SAMPLE scheme) and its sub-pixel / bounce-1 numbers are re-derived from it when an offset needs them.
-template <bool LAMBERT, bool SERIAL_RNG, class ACC>
+template <bool LAMBERT, bool SERIAL_RNG, bool WW, class ACC>
 GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, double spp, int x, int y, unsigned long long base,
                   Lane &L, LanePriv &lp, ACC &acc, LaneCounters &lc, TraceCounters &tc) {
     const DevCamera &cam = sv.cam;
@@ -282,7 +324,7 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
     // ---------------- TRACE (uniform over the wave) ----------------
     const bool tracing = (st0 == S_PRIMARY || st0 == S_BOUNCE || st0 == S_OFFSET);
     bool hit = false;
-    if (tracing) hit = intersect_ctx(sv, tx, ray, (st0 == S_BOUNCE) ? 0.0 : 0.25 / (double)max(w, h), nv, lc, tc);   // src/ray.h:33-35, :564
+    if (tracing) hit = intersect_ctx<WW>(sv, tx, ray, (st0 == S_BOUNCE) ? 0.0 : 0.25 / (double)max(w, h), nv, lc, tc);   // src/ray.h:33-35, :564
     // ---------------- consume the hit ----------------
     if (st0 == S_START) {
         act = ACT_PRIMARY_RAY;
@@ -589,7 +631,7 @@ __global__ __launch_bounds__(kBlock, WPS) void gdpt_render_phases(DevSceneView s
             q_next += (n_idle < avail) ? n_idle : avail;
         }
         if (!__any(L.st != S_DONE)) { if (exhausted) break; else continue; }
-        lane_step<LAMBERT, false>(sv, tx, a.max_depth, spp, x, y, base, L, lp, acc, lc, tc);
+        lane_step<LAMBERT, false, !LDS_SCENE>(sv, tx, a.max_depth, spp, x, y, base, L, lp, acc, lc, tc);
     }
     flush_counters(a, lc, tc, a.count != 0);
 }
@@ -642,7 +684,7 @@ __global__ __launch_bounds__(64) void gdpt_render_tile_stream_phases(DevSceneVie
             for (int x = x0; x < x1; x++) {
                 AccReg acc; acc.init();
                 L.s = 0; L.s_end = a.spp; L.st = S_START;
-                while (L.st != S_DONE) lane_step<LAMBERT, true>(sv, tx, a.max_depth, spp, x, y, 0ull, L, lp, acc, lc, tc);
+                while (L.st != S_DONE) lane_step<LAMBERT, true, true>(sv, tx, a.max_depth, spp, x, y, 0ull, L, lp, acc, lc, tc);
                 Accum sum = acc.result();
                 reduce_and_store(a, sum, 1, true, x, y, W);
             }
@@ -674,7 +716,7 @@ GD void grad_sample_eager(const DevSceneView &sv, const TraceCtx &tx, int max_de
     Ray ray = sample_primary(cam, (x + rng_x) / w, (y + rng_y) / h);
     const double rd_spread = 0.25 / (double)max(w, h);
     Vertex vertex;
-    if (!intersect_ctx(sv, tx, ray, rd_spread, vertex, lc, tc)) return;
+    if (!intersect_ctx<true>(sv, tx, ray, rd_spread, vertex, lc, tc)) return;
     Offset off[4];
     unsigned alive = 0;
 #pragma unroll 1
@@ -682,7 +724,7 @@ GD void grad_sample_eager(const DevSceneView &sv, const TraceCtx &tx, int max_de
         int ox = (k == 0) ? -1 : (k == 1 ? 1 : 0), oy = (k == 2) ? 1 : (k == 3 ? -1 : 0);
         Ray r = sample_primary(cam, ((x + ox) + rng_x) / w, ((y + oy) + rng_y) / h);
         Vertex ov;
-        bool ok = intersect_ctx(sv, tx, r, rd_spread, ov, lc, tc);
+        bool ok = intersect_ctx<true>(sv, tx, r, rd_spread, ov, lc, tc);
         if (ok && ov.material_id == vertex.material_id) {
             alive |= 1u << k;
             off[k].v = ov; off[k].dir = r.dir; off[k].jacob = 1.0;
@@ -704,7 +746,7 @@ GD void grad_sample_eager(const DevSceneView &sv, const TraceCtx &tx, int max_de
         if (bs.eta != 0) eta_scale /= (bs.eta * bs.eta);
         Ray bsdf_ray; bsdf_ray.org = vertex.position; bsdf_ray.dir = dir_bsdf; bsdf_ray.tnear = sv.isect_eps; bsdf_ray.tfar = __builtin_huge_val();
         Vertex bsdf_vertex;
-        bool hit = intersect_ctx(sv, tx, bsdf_ray, 0.0, bsdf_vertex, lc, tc);
+        bool hit = intersect_ctx<true>(sv, tx, bsdf_ray, 0.0, bsdf_vertex, lc, tc);
         if (alive) {
 #pragma unroll 1
             for (int k = 0; k < 4; k++)

@@ -26,6 +26,7 @@ struct RenderLaunch {
     int force_log2k;               // lanes per pixel = 2^force_log2k (-1 = automatic)
     int waves_per_simd;            // register budget variant of the phase kernel (2, 3 or 4)
     int num_cus;                   // compute units of the device (persistent grid size)
+    int blocks_per_cu;             // persistent blocks per CU (0 = default 2)
     double *partials;              // device, >= 15 * W * rows * 8 doubles (work-item partial sums)
     unsigned long long *queue_head;// device, work-queue head
 };

@@ -52,7 +52,7 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
             hipError_t me = hipMemsetAsync(a.queue_head, 0, sizeof(unsigned long long), stream);
             if (me != hipSuccess) throw std::runtime_error("launch_render: queue reset failed");
             long long waves_needed = (a.num_items + 63) / 64;
-            long long blocks = (long long)rl.num_cus * 2;              // 2 resident blocks per CU (LDS-bound); surplus blocks just queue
+            long long blocks = (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2);   // 2 resident blocks per CU (LDS-bound); surplus blocks just queue
             if (blocks > (waves_needed + 3) / 4) blocks = (waves_needed + 3) / 4;
             if (blocks < 1) blocks = 1;
             dim3 grid((unsigned)blocks);
