@@ -136,8 +136,10 @@ def main():
     # HBM bytes of the render kernel from the PMC passes committed under profiles/ (same command, same workload);
     # bench.py cannot run rocprofv3 around itself
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_b_hbm_traffic.json")
-    if world == 1 and args.spp == 16 and os.path.exists(tpath):
+    import glob
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    tpath = tfiles[-1] if tfiles else ""
+    if world == 1 and args.spp == 16 and tpath:
         try:
             traffic = json.load(open(tpath))["render_traffic_bytes_per_launch"]
         except Exception:
