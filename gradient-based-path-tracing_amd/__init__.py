@@ -62,6 +62,7 @@ def lib():
         L.gdpt_gradient_path_render.argtypes = [vp, C.POINTER(defs.GdptRenderParams), C.c_double, dp, dp, dp, dp, dp, dp,
                                                 C.POINTER(defs.GdptRenderStats), C.POINTER(defs.GdptPoissonStats)]
         L.gdpt_imwrite.argtypes = [C.c_char_p, C.c_int, C.c_int, dp]
+        L.gdpt_bvh_check.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int32)]
         _LIB = L
     return _LIB
 
@@ -210,6 +211,30 @@ def imwrite(filename, image):
     img = np.ascontiguousarray(image, dtype=np.float64)
     h, w, _ = img.shape
     _check(lib().gdpt_imwrite(os.fsencode(filename), w, h, _dp(img)))
+
+
+def bvh_check(bounds):
+    """Builds + verifies the traversal trees over n fp32 boxes (n x 6: min xyz, max xyz); host only.
+    Returns the stats dict of gdpt_bvh_check (include/gdpt.h)."""
+    b = np.ascontiguousarray(bounds, dtype=np.float32).reshape(-1, 6)
+    st = (C.c_int32 * 8)()
+    _check(lib().gdpt_bvh_check(b.ctypes.data_as(C.POINTER(C.c_float)), b.shape[0], st))
+    return dict(zip(("bvh2_nodes", "bvh2_depth", "wide_nodes", "wide_arity", "wide_stack_need", "leaves", "max_leaf_prims"), list(st)[:7]))
+
+
+def shape_triangle_bounds(scene_desc):
+    """fp32 boxes of every triangle of a SceneDesc, in shape order (what gdpt_scene_upload hands its BVH builder)."""
+    d = scene_desc.desc
+    out = []
+    for i in range(d.num_shapes):
+        sh = d.shapes[i]
+        if sh.num_triangles <= 0:
+            continue
+        pos = np.ctypeslib.as_array(sh.positions, shape=(sh.num_vertices, 3)).astype(np.float32)
+        idx = np.ctypeslib.as_array(sh.indices, shape=(sh.num_triangles, 3))
+        tri = pos[idx]                                   # T x 3 x 3
+        out.append(np.concatenate([tri.min(axis=1), tri.max(axis=1)], axis=1))
+    return np.concatenate(out, axis=0) if out else np.zeros((0, 6), np.float32)
 
 
 def build_arch():

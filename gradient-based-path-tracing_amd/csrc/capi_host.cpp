@@ -1,10 +1,14 @@
 // capi_host.cpp — host-only entry points of include/gdpt.h (scene ingest, image output, errors).
 #include "../../include/gdpt.h"
 #include "capi_common.h"
+#include "host/bvh.h"
 #include "host/image_io.h"
 #include "host/scene_loader.h"
 
+#include <cmath>
 #include <cstring>
+#include <vector>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -43,6 +47,89 @@ int gdpt_imwrite(const char *filename, int width, int height, const double *rgb)
     return gdpt::guarded([&]() {
         if (!filename || !rgb || width <= 0 || height <= 0) throw std::runtime_error("gdpt_imwrite: bad argument");
         gdpt::write_image(filename, width, height, rgb);
+    });
+}
+
+int gdpt_bvh_check(const float *bounds6, int n, int32_t stats[8]) {
+    return gdpt::guarded([&]() {
+        if (!bounds6 || n < 0 || !stats) throw std::runtime_error("gdpt_bvh_check: bad argument");
+        std::vector<gdpt::PrimBounds> b((size_t)n);
+        for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) { b[i].bmin[k] = bounds6[6 * i + k]; b[i].bmax[k] = bounds6[6 * i + 3 + k]; }
+        gdpt::BvhBuildResult r = gdpt::build_bvh(b);
+        gdpt::WideBvh wide = gdpt::collapse_for_traversal(r.nodes);
+        std::memset(stats, 0, 8 * sizeof(int32_t));
+        stats[0] = (int32_t)r.nodes.size(); stats[1] = r.depth;
+        stats[2] = (int32_t)wide.nodes.size(); stats[3] = wide.arity; stats[4] = wide.stack_need;
+        if (n == 0) return;
+        if ((int)r.order.size() != n) throw std::runtime_error("gdpt_bvh_check: leaf order does not cover the primitives");
+        std::vector<int> seen((size_t)n, 0);
+        int leaves = 0, max_leaf = 0;
+        // box of a leaf / subtree, checked against the box stored in the parent
+        struct Box { float lo[3], hi[3]; };
+        auto leaf_box = [&](int32_t child, std::vector<int> *mark) {
+            unsigned packed = ~(unsigned)child, first = packed >> 2, cnt = (packed & 3u) + 1u;
+            Box bx; for (int k = 0; k < 3; k++) { bx.lo[k] = INFINITY; bx.hi[k] = -INFINITY; }
+            if (first + cnt > (unsigned)n) throw std::runtime_error("gdpt_bvh_check: leaf range out of bounds");
+            for (unsigned i = 0; i < cnt; i++) {
+                uint32_t p = r.order[first + i];
+                if (mark) (*mark)[p]++;
+                for (int k = 0; k < 3; k++) { bx.lo[k] = std::min(bx.lo[k], b[p].bmin[k]); bx.hi[k] = std::max(bx.hi[k], b[p].bmax[k]); }
+            }
+            if (mark) { leaves++; max_leaf = std::max(max_leaf, (int)cnt); }
+            return bx;
+        };
+        auto inside = [](const Box &in, const float *lo, const float *hi) {
+            for (int k = 0; k < 3; k++) if (!(lo[k] <= in.lo[k] && in.hi[k] <= hi[k])) return false;
+            return true;
+        };
+        // BVH2: children have larger indices than parents? not guaranteed -> explicit post-order with a stack
+        std::vector<Box> box2(r.nodes.size());
+        {
+            std::vector<std::pair<int32_t, int>> st{{0, 0}};
+            while (!st.empty()) {
+                auto [ni, phase] = st.back(); st.pop_back();
+                const DevBvhNode &nd = r.nodes[(size_t)ni];
+                if (phase == 0) {
+                    st.push_back({ni, 1});
+                    if (nd.left >= 0) st.push_back({nd.left, 0});
+                    if (nd.right >= 0) st.push_back({nd.right, 0});
+                } else {
+                    Box acc; for (int k = 0; k < 3; k++) { acc.lo[k] = INFINITY; acc.hi[k] = -INFINITY; }
+                    const int32_t ch[2] = {nd.left, nd.right};
+                    const float *lo[2] = {nd.lmin, nd.rmin}, *hi[2] = {nd.lmax, nd.rmax};
+                    for (int c = 0; c < 2; c++) {
+                        if (ch[c] == GDPT_CHILD_EMPTY) continue;
+                        Box cb = ch[c] >= 0 ? box2[(size_t)ch[c]] : leaf_box(ch[c], &seen);
+                        if (!inside(cb, lo[c], hi[c])) throw std::runtime_error("gdpt_bvh_check: BVH2 child box does not enclose its subtree");
+                        for (int k = 0; k < 3; k++) { acc.lo[k] = std::min(acc.lo[k], lo[c][k]); acc.hi[k] = std::max(acc.hi[k], hi[c][k]); }
+                    }
+                    box2[(size_t)ni] = acc;
+                }
+            }
+        }
+        for (int i = 0; i < n; i++) if (seen[i] != 1) throw std::runtime_error("gdpt_bvh_check: a primitive is not in exactly one BVH2 leaf");
+        // wide form: children are emitted after their parents, so a reverse sweep sees children first
+        std::vector<Box> boxw(wide.nodes.size());
+        std::vector<int> seenw((size_t)n, 0);
+        int leaves_keep = leaves, max_keep = max_leaf;
+        for (size_t i = wide.nodes.size(); i-- > 0;) {
+            const DevBvh4Node &nd = wide.nodes[i];
+            Box acc; for (int k = 0; k < 3; k++) { acc.lo[k] = INFINITY; acc.hi[k] = -INFINITY; }
+            int cnt = 0;
+            for (int c = 0; c < 4; c++) {
+                if (nd.child[c] == GDPT_CHILD_EMPTY) continue;
+                cnt++;
+                if (nd.child[c] >= 0 && (size_t)nd.child[c] <= i) throw std::runtime_error("gdpt_bvh_check: wide child precedes its parent");
+                Box cb = nd.child[c] >= 0 ? boxw[(size_t)nd.child[c]] : leaf_box(nd.child[c], &seenw);
+                float lo[3] = {nd.lo[0][c], nd.lo[1][c], nd.lo[2][c]}, hi[3] = {nd.hi[0][c], nd.hi[1][c], nd.hi[2][c]};
+                if (!inside(cb, lo, hi)) throw std::runtime_error("gdpt_bvh_check: wide child box does not enclose its subtree");
+                for (int k = 0; k < 3; k++) { acc.lo[k] = std::min(acc.lo[k], lo[k]); acc.hi[k] = std::max(acc.hi[k], hi[k]); }
+            }
+            if (cnt > wide.arity) throw std::runtime_error("gdpt_bvh_check: wide node has more children than its arity");
+            boxw[i] = acc;
+        }
+        for (int i = 0; i < n; i++) if (seenw[i] != 1) throw std::runtime_error("gdpt_bvh_check: a primitive is not in exactly one wide leaf");
+        stats[5] = leaves_keep; stats[6] = max_keep;
     });
 }
 

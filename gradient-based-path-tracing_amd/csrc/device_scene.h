@@ -20,6 +20,16 @@ struct DevBvhNode {
     int32_t pad[2];
 };
 
+// BVH4 node, 128 B, 128-B aligned (scenes walked from HBM): four child boxes in SoA order, so one fetch decides four
+// subtrees and a ray needs about half as many dependent fetches as with DevBvhNode. Made by collapsing the BVH2
+// (host/bvh.cpp: collapse_bvh4); child encoding as above, unused slots hold GDPT_CHILD_EMPTY.
+struct DevBvh4Node {
+    float lo[3][4];      // lo[axis][child]
+    float hi[3][4];
+    int32_t child[4];
+    int32_t pad[4];
+};
+
 // Traversal record of one primitive, 48 B, in BVH leaf order.
 // Triangle: v0, e1 = fl(v1-v0), e2 = fl(v2-v0) in fp32; gid = global triangle id (index into DevTriShade).
 // Sphere:   gid = GDPT_SPHERE_FLAG | sphere index; the fp32 fields are unused (fp64 data in DevSphere).
@@ -72,6 +82,7 @@ struct DevCamera {
 struct DevSceneView {
     DevCamera cam;
     const DevBvhNode *nodes;
+    const DevBvh4Node *nodes4;              // wide form of the same tree (HBM-resident scenes)
     const DevPrim *prims;
     const DevTriShade *tris;
     const DevSphere *spheres;
@@ -79,7 +90,7 @@ struct DevSceneView {
     const double *light_intensity;          // 3 per area light
     const DevImage *images;
     const double *texels;
-    int32_t num_nodes, num_prims, num_tris, num_spheres;
+    int32_t num_nodes, num_nodes4, num_prims, num_tris, num_spheres;
     int32_t num_materials, num_lights, num_images;
     int32_t max_depth, rr_depth;
     int32_t all_textures_constant;          // no image / checkerboard texture anywhere: uv and footprints are unobservable

@@ -176,6 +176,10 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
                 if (n.rmin[k] <= n.rmax[k]) { n.rmin[k] -= pad; n.rmax[k] += pad; }
             }
     }
+    // wide form for scenes walked from HBM (same padded boxes); narrower nodes if the stack bound would not hold
+    gdpt::WideBvh wide = gdpt::collapse_for_traversal(bvh.nodes);
+    if (wide.stack_need > GDPT_BVH_MAX_DEPTH) throw std::runtime_error("gdpt_scene_upload: BVH deeper than the traversal stack (builder bug)");
+    const std::vector<DevBvh4Node> &nodes4 = wide.nodes;
     std::vector<DevPrim> prims(prim_in.size());
     for (size_t i = 0; i < bvh.order.size(); i++) prims[i] = prim_in[bvh.order[i]];
     sc->bvh_depth = bvh.depth;
@@ -225,6 +229,7 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     }
     v.cam.width = cam.width; v.cam.height = cam.height; v.cam.filter_type = cam.filter_type; v.cam.filter_param = cam.filter_param;
     v.nodes = sc->keep(upload(bvh.nodes));
+    v.nodes4 = sc->keep(upload(nodes4));
     v.prims = sc->keep(upload(prims));
     v.tris = sc->keep(upload(tris));
     v.spheres = sc->keep(upload(spheres));
@@ -232,7 +237,7 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     v.light_intensity = sc->keep(upload(light_intensity));
     v.images = sc->keep(upload(images));
     v.texels = sc->keep(upload(texels));
-    v.num_nodes = (int)bvh.nodes.size(); v.num_prims = (int)prims.size();
+    v.num_nodes = (int)bvh.nodes.size(); v.num_nodes4 = (int)nodes4.size(); v.num_prims = (int)prims.size();
     v.num_tris = (int)tris.size(); v.num_spheres = (int)spheres.size();
     v.num_materials = desc->num_materials; v.num_lights = desc->num_lights; v.num_images = desc->num_images;
     v.max_depth = desc->max_depth; v.rr_depth = desc->rr_depth;

@@ -126,6 +126,7 @@ GD void acc_no_offsets(ACC &a, D3 radiance, D3 contrib, double prob, double spp,
 // ------------------------------------------------------------------------------------------------
 struct TraceCtx {
     const DevBvhNode *nodes;
+    const DevBvh4Node *nodes4;
     const DevPrim *prims;
     const DevTriShade *tris;
     const GdptMaterial *materials;
@@ -180,25 +181,40 @@ GD Hit closest_hit_ctx(const DevSceneView &sv, const TraceCtx &tx, const float o
         }
         return best;
     }
-    // "while-while" traversal: all lanes first walk inner nodes until each holds a leaf (or has finished), then the
-    // leaves are intersected together — keeps the box-test code and the triangle-test code from serialising each other.
+    // Scenes walked from HBM: BVH4 nodes (half the dependent fetches of the BVH2), "while-while" order — all lanes first
+    // walk inner nodes until each holds a leaf (or has finished), then the leaves are intersected together, which keeps
+    // the box-test code and the triangle-test code from serialising each other.
     int sp = 0, cur = 0;
     bool done = false;
     for (;;) {
         while (cur >= 0 && !done) {
-            const DevBvhNode &n = tx.nodes[cur];
+            const DevBvh4Node &n = tx.nodes4[cur];
             if (tx.count) tc.nodes++;
-            float tb = best.t, tl, tr;
-            bool hl = (n.left != GDPT_CHILD_EMPTY) && box_hit(n.lmin, n.lmax, oi, inv, tnear, tb, tl);
-            bool hr = (n.right != GDPT_CHILD_EMPTY) && box_hit(n.rmin, n.rmax, oi, inv, tnear, tb, tr);
-            if (hl && hr) {
-                int nearc = n.left, farc = n.right;
-                if (tr < tl) { nearc = n.right; farc = n.left; }
-                tx.stack[sp * tx.stride] = farc; sp++;
-                cur = nearc;
-            } else if (hl) cur = n.left;
-            else if (hr) cur = n.right;
-            else if (sp > 0) { sp--; cur = tx.stack[sp * tx.stride]; }
+            const float tb = best.t;
+            const int c0 = n.child[0], c1 = n.child[1], c2 = n.child[2], c3 = n.child[3];
+            // key = entry distance (>= 0, so its bit pattern orders like the float) with the slot in the low two bits
+            unsigned key[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                float t0 = tnear, t1 = tb;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    float a = fmaf(n.lo[k][c], inv[k], -oi[k]), b = fmaf(n.hi[k][c], inv[k], -oi[k]);
+                    t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
+                }
+                const bool h = (n.child[c] != GDPT_CHILD_EMPTY) && (t0 <= t1 * 1.000001f);
+                key[c] = h ? ((__float_as_uint(t0) & ~3u) | (unsigned)c) : 0xFFFFFFFFu;
+            }
+#define GDPT_CSWAP(i, j) { unsigned lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
+            GDPT_CSWAP(0, 1) GDPT_CSWAP(2, 3) GDPT_CSWAP(0, 2) GDPT_CSWAP(1, 3) GDPT_CSWAP(1, 2)
+#undef GDPT_CSWAP
+            auto child_of = [&](unsigned k) { const unsigned c = k & 3u; return c == 0 ? c0 : (c == 1 ? c1 : (c == 2 ? c2 : c3)); };
+            if (key[0] != 0xFFFFFFFFu) {
+                if (key[3] != 0xFFFFFFFFu) { tx.stack[sp * tx.stride] = child_of(key[3]); sp++; }
+                if (key[2] != 0xFFFFFFFFu) { tx.stack[sp * tx.stride] = child_of(key[2]); sp++; }
+                if (key[1] != 0xFFFFFFFFu) { tx.stack[sp * tx.stride] = child_of(key[1]); sp++; }
+                cur = child_of(key[0]);
+            } else if (sp > 0) { sp--; cur = tx.stack[sp * tx.stride]; }
             else done = true;
         }
         if (done) break;
@@ -526,12 +542,12 @@ GD TraceCtx setup_trace(const DevSceneView &sv, unsigned char *s_scene, int *s_s
         for (int i = tid; i < tw; i += nthreads) dst[nw + pw + i] = s2[i];
         for (int i = tid; i < mw; i += nthreads) dst[nw + pw + tw + i] = s3[i];
         __syncthreads();
-        tx.nodes = (const DevBvhNode *)s_scene;
+        tx.nodes = (const DevBvhNode *)s_scene; tx.nodes4 = nullptr;
         tx.prims = (const DevPrim *)(s_scene + (size_t)nw * 4);
         tx.tris = (const DevTriShade *)(s_scene + (size_t)(nw + pw) * 4);
         tx.materials = (const GdptMaterial *)(s_scene + (size_t)(nw + pw + tw) * 4);
     } else {
-        tx.nodes = sv.nodes; tx.prims = sv.prims; tx.tris = sv.tris; tx.materials = sv.materials;
+        tx.nodes = sv.nodes; tx.nodes4 = sv.nodes4; tx.prims = sv.prims; tx.tris = sv.tris; tx.materials = sv.materials;
     }
     return tx;
 }

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <utility>
 
 namespace gdpt {
 
@@ -180,6 +181,102 @@ BvhBuildResult build_bvh(const std::vector<PrimBounds> &bounds) {
     bld.build_inner(0, n, 0, &depth);
     bld.out.depth = depth;
     return std::move(bld.out);
+}
+
+std::vector<DevBvh4Node> collapse_bvh4(const std::vector<DevBvhNode> &nodes, int max_children, int stack_slots, int *stack_need) {
+    std::vector<DevBvh4Node> out;
+    if (stack_need) *stack_need = 0;
+    if (nodes.empty()) return out;
+    max_children = std::min(4, std::max(2, max_children));
+    struct Ref { float lo[3], hi[3]; int32_t child; };
+    auto area = [](const Ref &r) {
+        float dx = r.hi[0] - r.lo[0], dy = r.hi[1] - r.lo[1], dz = r.hi[2] - r.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto refs_of = [&](int32_t ni, Ref *dst) {       // child refs of BVH2 node ni (EMPTY slots skipped)
+        const DevBvhNode &n = nodes[(size_t)ni];
+        int c = 0;
+        if (n.left != GDPT_CHILD_EMPTY) { for (int k = 0; k < 3; k++) { dst[c].lo[k] = n.lmin[k]; dst[c].hi[k] = n.lmax[k]; } dst[c].child = n.left; c++; }
+        if (n.right != GDPT_CHILD_EMPTY) { for (int k = 0; k < 3; k++) { dst[c].lo[k] = n.rmin[k]; dst[c].hi[k] = n.rmax[k]; } dst[c].child = n.right; c++; }
+        return c;
+    };
+    // d2[i]: inner-node levels below and including BVH2 node i = the stack a purely binary walk of that subtree needs.
+    std::vector<int> d2(nodes.size(), 0);
+    {
+        std::vector<std::pair<int32_t, int>> st{{0, 0}};
+        while (!st.empty()) {
+            auto [ni, phase] = st.back(); st.pop_back();
+            const DevBvhNode &n = nodes[(size_t)ni];
+            if (phase == 0) {
+                st.push_back({ni, 1});
+                if (n.left >= 0) st.push_back({n.left, 0});
+                if (n.right >= 0) st.push_back({n.right, 0});
+            } else d2[(size_t)ni] = 1 + std::max(n.left >= 0 ? d2[(size_t)n.left] : 0, n.right >= 0 ? d2[(size_t)n.right] : 0);
+        }
+    }
+    // A node that holds cnt children pushes up to cnt-1 entries before it descends, so each child inherits the node's
+    // slot budget minus cnt-1. A subtree whose binary depth fits its budget can always be finished with arity 2, so the
+    // widest arity whose children all satisfy d2(child) <= budget-(cnt-1) is taken: the tree is 4-wide wherever the
+    // SAH tree is reasonably balanced and narrows only along unusually deep paths.
+    struct Item { int32_t node; int budget; };
+    std::vector<Item> queue{{0, stack_slots}};
+    out.emplace_back();
+    for (size_t qi = 0; qi < queue.size(); qi++) {
+        Ref refs[4];
+        int cnt = 0;
+        for (int arity = max_children; arity >= 2; arity--) {
+            cnt = refs_of(queue[qi].node, refs);
+            while (cnt < arity) {
+                int best = -1; float best_area = -1.f;
+                for (int i = 0; i < cnt; i++) if (refs[i].child >= 0) { float a = area(refs[i]); if (a > best_area) { best_area = a; best = i; } }
+                if (best < 0) break;
+                Ref sub[2];
+                int sc = refs_of(refs[best].child, sub);
+                if (sc == 0) { refs[best] = refs[cnt - 1]; cnt--; continue; }
+                refs[best] = sub[0];
+                if (sc == 2) refs[cnt++] = sub[1];
+            }
+            bool fits = (cnt - 1 <= queue[qi].budget);
+            for (int i = 0; i < cnt; i++) if (refs[i].child >= 0 && d2[(size_t)refs[i].child] > queue[qi].budget - (cnt - 1)) fits = false;
+            if (fits) break;      // arity 2 of a subtree with d2 <= budget always fits
+        }
+        DevBvh4Node nd;
+        for (int c = 0; c < 4; c++) {
+            for (int k = 0; k < 3; k++) { nd.lo[k][c] = std::numeric_limits<float>::infinity(); nd.hi[k][c] = -std::numeric_limits<float>::infinity(); }
+            nd.child[c] = GDPT_CHILD_EMPTY; nd.pad[c] = 0;
+        }
+        for (int c = 0; c < cnt; c++) {
+            for (int k = 0; k < 3; k++) { nd.lo[k][c] = refs[c].lo[k]; nd.hi[k][c] = refs[c].hi[k]; }
+            if (refs[c].child >= 0) {
+                nd.child[c] = (int32_t)out.size();
+                queue.push_back({refs[c].child, queue[qi].budget - (cnt - 1)});
+                out.emplace_back();
+            } else nd.child[c] = refs[c].child;
+        }
+        out[qi] = nd;
+    }
+    if (stack_need) {
+        // need(node) = (children - 1) + max over inner children of need(child); children come after parents
+        std::vector<int> need(out.size(), 0);
+        for (size_t i = out.size(); i-- > 0;) {
+            int cnt = 0, sub = 0;
+            for (int c = 0; c < 4; c++) if (out[i].child[c] != GDPT_CHILD_EMPTY) { cnt++; if (out[i].child[c] >= 0) sub = std::max(sub, need[(size_t)out[i].child[c]]); }
+            need[i] = std::max(0, cnt - 1) + sub;
+        }
+        *stack_need = need[0];
+    }
+    return out;
+}
+
+WideBvh collapse_for_traversal(const std::vector<DevBvhNode> &nodes) {
+    WideBvh w;
+    w.nodes = collapse_bvh4(nodes, 4, GDPT_BVH_MAX_DEPTH, &w.stack_need);
+    for (const DevBvh4Node &n : w.nodes) {
+        int cnt = 0;
+        for (int c = 0; c < 4; c++) cnt += (n.child[c] != GDPT_CHILD_EMPTY);
+        w.arity = std::max(w.arity, cnt);
+    }
+    return w;
 }
 
 } // namespace gdpt

@@ -19,4 +19,14 @@ struct BvhBuildResult {
 // `bounds[i]` must enclose primitive i (conservatively). Leaves hold 1..GDPT_LEAF_MAX_PRIMS primitives.
 BvhBuildResult build_bvh(const std::vector<PrimBounds> &bounds);
 
+// Collapses a BVH2 into nodes of up to `max_children` (2..4) children: the child with the largest surface area is
+// replaced by its own two children until the node is full. Nodes are emitted breadth-first (the top of the tree is
+// contiguous). The traversal stack bound stays within `stack_slots` (arity drops locally along over-deep paths; the
+// BVH2's own depth must fit); `*stack_need` receives the bound actually reached.
+std::vector<DevBvh4Node> collapse_bvh4(const std::vector<DevBvhNode> &nodes, int max_children, int stack_slots, int *stack_need);
+
+// The wide tree the device walks (stack bound <= GDPT_BVH_MAX_DEPTH slots); arity = widest node present.
+struct WideBvh { std::vector<DevBvh4Node> nodes; int arity = 0, stack_need = 0; };
+WideBvh collapse_for_traversal(const std::vector<DevBvhNode> &nodes);
+
 } // namespace gdpt

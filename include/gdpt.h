@@ -218,6 +218,14 @@ int gdpt_gradient_path_render(GdptScene *scene, const GdptRenderParams *params, 
 /* By suffix: ".pfm" (fp32, header "PF\nW H\n-1\n", rows as stored) or ".exr" (fp16 RGB scanline). */
 int gdpt_imwrite(const char *filename, int width, int height, const double *rgb);
 
+/* ---- diagnostics (host only, no GPU) ----
+ * Builds the acceleration structure that gdpt_scene_upload would build over `n` primitive boxes (bounds6 = n x
+ * {min xyz, max xyz}, fp32) — the replacement for the reference's Embree commit, src/scene.cpp:20-31 — and verifies it:
+ * every primitive sits in exactly one leaf, every child box encloses the boxes below it, in the BVH2 and in the
+ * collapsed wide form. stats: [0] BVH2 nodes, [1] BVH2 depth, [2] wide nodes, [3] wide node arity used (2..4),
+ * [4] traversal-stack bound of the wide form, [5] leaves, [6] max primitives per leaf, [7] 0. */
+int gdpt_bvh_check(const float *bounds6, int n, int32_t stats[8]);
+
 const char *gdpt_last_error(void);
 /* "gfx950" etc. of the device the library's kernels were built for, and the running device name. */
 const char *gdpt_build_arch(void);

@@ -1,0 +1,57 @@
+"""Host acceleration-structure builder (replacement of the reference's Embree commit, src/scene.cpp:20-31):
+gdpt_bvh_check builds the BVH2 and its collapsed wide form and verifies coverage / enclosure itself; these tests
+drive it with random, degenerate and real-scene inputs. CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import gdpt_amd as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rand_boxes(rng, n, spread=10.0, size=0.5):
+    c = rng.uniform(-spread, spread, size=(n, 3))
+    h = rng.uniform(0, size, size=(n, 3))
+    return np.concatenate([c - h, c + h], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 64, 1000, 20000])
+def test_random_boxes(n):
+    st = G.bvh_check(rand_boxes(np.random.default_rng(n), n))
+    assert st["max_leaf_prims"] <= 4
+    assert 1 <= st["wide_arity"] <= 4
+    assert st["wide_stack_need"] <= 32 and st["bvh2_depth"] <= 32
+    if n > 4:
+        assert st["wide_nodes"] < st["bvh2_nodes"]
+
+
+def test_empty():
+    st = G.bvh_check(np.zeros((0, 6), np.float32))
+    assert st["bvh2_nodes"] == 0 and st["wide_nodes"] == 0
+
+
+def test_identical_centroids_and_flat_boxes():
+    # all centroids coincide (SAH has nothing to split on) and zero-thickness boxes
+    b = np.tile(np.array([[0, 0, 0, 1, 1, 0]], np.float32), (37, 1))
+    st = G.bvh_check(b)
+    assert st["bvh2_depth"] <= 32 and st["leaves"] >= 10
+
+
+def test_long_diagonal_chain():
+    # boxes on a line with geometrically growing sizes: drives the builder towards deep, unbalanced trees
+    n = 4000
+    t = (1.01 ** np.arange(n)).astype(np.float64)
+    b = np.stack([t, t, t, t * 1.001, t * 1.001, t * 1.001], axis=1).astype(np.float32)
+    st = G.bvh_check(b)
+    assert st["bvh2_depth"] <= 32 and st["wide_stack_need"] <= 32
+
+
+@pytest.mark.parametrize("scene", ["cbox/cbox_gdpt.xml", "sponza/sponza.xml", "disney_bsdf_test/disney_bsdf.xml"])
+def test_scene_geometry(scene):
+    sd = G.parse_scene(os.path.join(ROOT, "scenes", scene))
+    b = G.shape_triangle_bounds(sd)
+    st = G.bvh_check(b)
+    print(scene, st)
+    assert st["leaves"] > 0 and st["wide_stack_need"] <= 32
