@@ -129,8 +129,9 @@ def main():
     import ctypes as C
     G._check(G.lib().gdpt_render_device(scene.handle, C.byref(p), *[C.c_void_p(ptr(bufs[k])) for k in names],
                                         C.c_void_p(stream), C.byref(cs)))
-    # bytes = rays*64 (ray+hit records) + nodes*64 + prims*48 + bounces*320 (path state r/w)
-    alg_bytes = cs.rays * 64 + cs.nodes_visited * 64 + cs.tris_tested * 48 + cs.bounces * 320
+    # bytes = rays*64 (ray+hit records) + nodes*node_bytes + prims*48 + bounces*320 (path state r/w);
+    # node_bytes = 64 for a BVH2 node (the survey's figure), 128 for the BVH4 node this scene is walked in
+    alg_bytes = cs.rays * 64 + cs.nodes_visited * cs.node_bytes + cs.tris_tested * 48 + cs.bounces * 320
     achieved = alg_bytes / (render_ms_avg * 1e-3) / 1e9 if render_ms_avg > 0 else 0.0
 
     # HBM bytes of the render kernel from the PMC passes committed under profiles/ (same command, same workload);
@@ -165,7 +166,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "gdpt_render_phases", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": render_ms_avg,
-                     "nodes_per_ray": cs.nodes_visited / max(1, cs.rays), "prims_per_ray": cs.tris_tested / max(1, cs.rays)},
+                     "nodes_per_ray": cs.nodes_visited / max(1, cs.rays), "node_bytes": cs.node_bytes, "prims_per_ray": cs.tris_tested / max(1, cs.rays)},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

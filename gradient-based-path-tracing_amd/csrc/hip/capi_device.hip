@@ -40,6 +40,7 @@ struct GdptScene {
     int device = 0;
     DevSceneView view{};
     int bvh_depth = 0;
+    int wide_stack_need = 0;
     int scene_spp = 0;             // <sampler sampleCount> of the description (default spp)
     bool one_sided = true, lambert_only = true;
     std::vector<void *> allocations;
@@ -180,6 +181,7 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     gdpt::WideBvh wide = gdpt::collapse_for_traversal(bvh.nodes);
     if (wide.stack_need > GDPT_BVH_MAX_DEPTH) throw std::runtime_error("gdpt_scene_upload: BVH deeper than the traversal stack (builder bug)");
     const std::vector<DevBvh4Node> &nodes4 = wide.nodes;
+    sc->wide_stack_need = wide.stack_need;
     std::vector<DevPrim> prims(prim_in.size());
     for (size_t i = 0; i < bvh.order.size(); i++) prims[i] = prim_in[bvh.order[i]];
     sc->bvh_depth = bvh.depth;
@@ -298,7 +300,6 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.force_eager = env_int("GDPT_FORCE_EAGER", 0) != 0;           // tuning / A-B knobs (undocumented defaults are the product path)
     rl.thresh_a = env_int("GDPT_THRESH_A", 0); rl.thresh_c = env_int("GDPT_THRESH_C", 0);
     rl.force_log2k = env_int("GDPT_LOG2K", -1);
-    rl.waves_per_simd = env_int("GDPT_WPS", 2);
     rl.num_cus = sc->num_cus;
     rl.blocks_per_cu = env_int("GDPT_BLOCKS_PER_CU", 0);
     {
@@ -311,6 +312,8 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
         rl.partials = sc->d_partials; rl.queue_head = sc->d_queue;
     }
     if (env_int("GDPT_NO_LDS_SCENE", 0)) rl.scene_fits_lds = false;
+    rl.lds_wide = rl.scene_fits_lds && env_int("GDPT_LDS_WIDE", 1) != 0 &&
+                  gdpt::scene_fits_lds_wide(sc->view.num_nodes4, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->wide_stack_need);
     ck(hipMemsetAsync(sc->d_counters, 0, sizeof(gdpt::RenderCounters), stream), "hipMemsetAsync(counters)");
     if (stats) ck(hipEventRecord(sc->ev0, stream), "hipEventRecord");
     gdpt::launch_render(sc->view, rl, stream);
@@ -325,6 +328,9 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
         stats->nonfinite_samples = sc->h_counters->nonfinite;
         stats->nodes_visited = sc->h_counters->nodes; stats->tris_tested = sc->h_counters->prims;
         stats->render_ms = ms;
+        // only the persistent kernel over an LDS-resident scene can still walk the BVH2 form
+        const bool lds_kernel = rl.one_sided_materials && !rl.force_eager && b.rng == GDPT_RNG_SAMPLE && rl.scene_fits_lds;
+        stats->node_bytes = (lds_kernel && !rl.lds_wide) ? sizeof(DevBvhNode) : sizeof(DevBvh4Node);
     }
 }
 

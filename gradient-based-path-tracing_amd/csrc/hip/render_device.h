@@ -136,9 +136,51 @@ struct TraceCtx {
     bool need_uv;     // wave-uniform: some texture is not constant (uv / footprint are observable)
 };
 
-// WW: "while-while" loop order (large scenes walked from HBM: +6 % on sponza) vs. one node or leaf per trip (scenes
-// resident in LDS: +5 % on cbox).
-template <bool WW>
+// One BVH4 node: tests the four child boxes and returns the hit children sorted near to far. key = entry distance
+// (>= 0, so its bit pattern orders like the float) with the child slot in the low two bits; 0xFFFFFFFF = missed.
+struct WideVisit { unsigned key[4]; int c0, c1, c2, c3; };
+constexpr unsigned kMissKey = 0xFFFFFFFFu;
+GD int wide_child(const WideVisit &w, unsigned k) { const unsigned c = k & 3u; return c == 0 ? w.c0 : (c == 1 ? w.c1 : (c == 2 ? w.c2 : w.c3)); }
+GD void visit_wide(const DevBvh4Node &n, const float oi[3], const float inv[3], float tnear, float tb, WideVisit &w) {
+    w.c0 = n.child[0]; w.c1 = n.child[1]; w.c2 = n.child[2]; w.c3 = n.child[3];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float t0 = tnear, t1 = tb;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float a = fmaf(n.lo[k][c], inv[k], -oi[k]), b = fmaf(n.hi[k][c], inv[k], -oi[k]);
+            t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));       // NaN (inf - inf, 0*inf) is dropped by fmin/fmax
+        }
+        const bool h = (n.child[c] != GDPT_CHILD_EMPTY) && (t0 <= t1 * 1.000001f);   // see box_hit
+        w.key[c] = h ? ((__float_as_uint(t0) & ~3u) | (unsigned)c) : kMissKey;
+    }
+#define GDPT_CSWAP(i, j) { unsigned lo_ = min(w.key[i], w.key[j]), hi_ = max(w.key[i], w.key[j]); w.key[i] = lo_; w.key[j] = hi_; }
+    GDPT_CSWAP(0, 1) GDPT_CSWAP(2, 3) GDPT_CSWAP(0, 2) GDPT_CSWAP(1, 3) GDPT_CSWAP(1, 2)
+#undef GDPT_CSWAP
+}
+
+// A leaf holds 1..4 primitive records. All of them are fetched before the first test (indices clamped to the leaf, so
+// short leaves re-read their last record): the leaf then costs one memory latency instead of one per primitive.
+GD void test_leaf(const DevSceneView &sv, const TraceCtx &tx, int cur, const float o[3], const float d[3], float tnear, float tfar,
+                  Hit &best, TraceCounters &tc) {
+    const unsigned packed = ~(unsigned)cur;
+    const unsigned first = packed >> 2, last = packed & 3u;      // last = count - 1
+    const DevPrim p0 = tx.prims[first];
+    const DevPrim p1 = tx.prims[first + min(1u, last)];
+    const DevPrim p2 = tx.prims[first + min(2u, last)];
+    const DevPrim p3 = tx.prims[first + last];
+    if (tx.count) tc.prims += last + 1u;
+    test_prim(sv, p0, o, d, tnear, tfar, best);
+    if (last >= 1u) test_prim(sv, p1, o, d, tnear, tfar, best);
+    if (last >= 2u) test_prim(sv, p2, o, d, tnear, tfar, best);
+    if (last >= 3u) test_prim(sv, p3, o, d, tnear, tfar, best);
+}
+
+// Closest hit (definition: device_trace.h). WIDE: walk the BVH4 form (half the dependent node fetches of the BVH2).
+// WW: "while-while" loop order — all lanes first walk inner nodes until each holds a leaf (or has finished), then the
+// leaves are intersected together (large scenes walked from HBM: +6 % on sponza) — vs. one node or leaf per trip
+// (scenes resident in LDS: +5 % on cbox).
+template <bool WW, bool WIDE>
 GD Hit closest_hit_ctx(const DevSceneView &sv, const TraceCtx &tx, const float o[3], const float d[3], float tnear, float tfar, TraceCounters &tc) {
     Hit best; best.gid = -1; best.t = tfar; best.u = best.v = 0; best.ngx = best.ngy = best.ngz = 0;
     if (sv.num_nodes == 0) return best;
@@ -149,12 +191,58 @@ GD Hit closest_hit_ctx(const DevSceneView &sv, const TraceCtx &tx, const float o
     // coordinate or the other axes reject)
 #pragma unroll
     for (int k = 0; k < 3; k++) if (d[k] == 0.0f) { inv[k] = __builtin_nanf(""); oi[k] = __builtin_nanf(""); }
+    int sp = 0, cur = 0;
     if (!WW) {
-        int sp = 0, cur = 0;
         for (;;) {
             if (cur >= 0) {
-                const DevBvhNode &n = tx.nodes[cur];
                 if (tx.count) tc.nodes++;
+                if (WIDE) {
+                    WideVisit w;
+                    visit_wide(tx.nodes4[cur], oi, inv, tnear, best.t, w);
+                    if (w.key[0] != kMissKey) {
+                        if (w.key[3] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[3]); sp++; }
+                        if (w.key[2] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[2]); sp++; }
+                        if (w.key[1] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[1]); sp++; }
+                        cur = wide_child(w, w.key[0]);
+                        continue;
+                    }
+                } else {
+                    const DevBvhNode &n = tx.nodes[cur];
+                    float tb = best.t, tl, tr;
+                    bool hl = (n.left != GDPT_CHILD_EMPTY) && box_hit(n.lmin, n.lmax, oi, inv, tnear, tb, tl);
+                    bool hr = (n.right != GDPT_CHILD_EMPTY) && box_hit(n.rmin, n.rmax, oi, inv, tnear, tb, tr);
+                    if (hl && hr) {
+                        int nearc = n.left, farc = n.right;
+                        if (tr < tl) { nearc = n.right; farc = n.left; }
+                        tx.stack[sp * tx.stride] = farc; sp++;
+                        cur = nearc;
+                        continue;
+                    } else if (hl) { cur = n.left; continue; }
+                    else if (hr) { cur = n.right; continue; }
+                }
+            } else test_leaf(sv, tx, cur, o, d, tnear, tfar, best, tc);
+            if (sp == 0) break;
+            sp--;
+            cur = tx.stack[sp * tx.stride];
+        }
+        return best;
+    }
+    bool done = false;
+    for (;;) {
+        while (cur >= 0 && !done) {
+            if (tx.count) tc.nodes++;
+            if (WIDE) {
+                WideVisit w;
+                visit_wide(tx.nodes4[cur], oi, inv, tnear, best.t, w);
+                if (w.key[0] != kMissKey) {
+                    if (w.key[3] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[3]); sp++; }
+                    if (w.key[2] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[2]); sp++; }
+                    if (w.key[1] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[1]); sp++; }
+                    cur = wide_child(w, w.key[0]);
+                } else if (sp > 0) { sp--; cur = tx.stack[sp * tx.stride]; }
+                else done = true;
+            } else {
+                const DevBvhNode &n = tx.nodes[cur];
                 float tb = best.t, tl, tr;
                 bool hl = (n.left != GDPT_CHILD_EMPTY) && box_hit(n.lmin, n.lmax, oi, inv, tnear, tb, tl);
                 bool hr = (n.right != GDPT_CHILD_EMPTY) && box_hit(n.rmin, n.rmax, oi, inv, tnear, tb, tr);
@@ -163,70 +251,14 @@ GD Hit closest_hit_ctx(const DevSceneView &sv, const TraceCtx &tx, const float o
                     if (tr < tl) { nearc = n.right; farc = n.left; }
                     tx.stack[sp * tx.stride] = farc; sp++;
                     cur = nearc;
-                    continue;
-                } else if (hl) { cur = n.left; continue; }
-                else if (hr) { cur = n.right; continue; }
-            } else {
-                unsigned packed = ~(unsigned)cur;
-                unsigned first = packed >> 2, cnt = (packed & 3u) + 1u;
-#pragma unroll 1
-                for (unsigned i = 0; i < cnt; i++) {
-                    if (tx.count) tc.prims++;
-                    test_prim(sv, tx.prims[first + i], o, d, tnear, tfar, best);
-                }
+                } else if (hl) cur = n.left;
+                else if (hr) cur = n.right;
+                else if (sp > 0) { sp--; cur = tx.stack[sp * tx.stride]; }
+                else done = true;
             }
-            if (sp == 0) break;
-            sp--;
-            cur = tx.stack[sp * tx.stride];
-        }
-        return best;
-    }
-    // Scenes walked from HBM: BVH4 nodes (half the dependent fetches of the BVH2), "while-while" order — all lanes first
-    // walk inner nodes until each holds a leaf (or has finished), then the leaves are intersected together, which keeps
-    // the box-test code and the triangle-test code from serialising each other.
-    int sp = 0, cur = 0;
-    bool done = false;
-    for (;;) {
-        while (cur >= 0 && !done) {
-            const DevBvh4Node &n = tx.nodes4[cur];
-            if (tx.count) tc.nodes++;
-            const float tb = best.t;
-            const int c0 = n.child[0], c1 = n.child[1], c2 = n.child[2], c3 = n.child[3];
-            // key = entry distance (>= 0, so its bit pattern orders like the float) with the slot in the low two bits
-            unsigned key[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                float t0 = tnear, t1 = tb;
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    float a = fmaf(n.lo[k][c], inv[k], -oi[k]), b = fmaf(n.hi[k][c], inv[k], -oi[k]);
-                    t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
-                }
-                const bool h = (n.child[c] != GDPT_CHILD_EMPTY) && (t0 <= t1 * 1.000001f);
-                key[c] = h ? ((__float_as_uint(t0) & ~3u) | (unsigned)c) : 0xFFFFFFFFu;
-            }
-#define GDPT_CSWAP(i, j) { unsigned lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
-            GDPT_CSWAP(0, 1) GDPT_CSWAP(2, 3) GDPT_CSWAP(0, 2) GDPT_CSWAP(1, 3) GDPT_CSWAP(1, 2)
-#undef GDPT_CSWAP
-            auto child_of = [&](unsigned k) { const unsigned c = k & 3u; return c == 0 ? c0 : (c == 1 ? c1 : (c == 2 ? c2 : c3)); };
-            if (key[0] != 0xFFFFFFFFu) {
-                if (key[3] != 0xFFFFFFFFu) { tx.stack[sp * tx.stride] = child_of(key[3]); sp++; }
-                if (key[2] != 0xFFFFFFFFu) { tx.stack[sp * tx.stride] = child_of(key[2]); sp++; }
-                if (key[1] != 0xFFFFFFFFu) { tx.stack[sp * tx.stride] = child_of(key[1]); sp++; }
-                cur = child_of(key[0]);
-            } else if (sp > 0) { sp--; cur = tx.stack[sp * tx.stride]; }
-            else done = true;
         }
         if (done) break;
-        {
-            unsigned packed = ~(unsigned)cur;
-            unsigned first = packed >> 2, cnt = (packed & 3u) + 1u;
-#pragma unroll 1
-            for (unsigned i = 0; i < cnt; i++) {
-                if (tx.count) tc.prims++;
-                test_prim(sv, tx.prims[first + i], o, d, tnear, tfar, best);
-            }
-        }
+        test_leaf(sv, tx, cur, o, d, tnear, tfar, best, tc);
         if (sp == 0) break;
         sp--;
         cur = tx.stack[sp * tx.stride];
@@ -234,12 +266,12 @@ GD Hit closest_hit_ctx(const DevSceneView &sv, const TraceCtx &tx, const float o
     return best;
 }
 
-template <bool WW>
+template <bool WW, bool WIDE>
 GD bool intersect_ctx(const DevSceneView &sv, const TraceCtx &tx, const Ray &ray, double rd_spread, Vertex &v, LaneCounters &lc, TraceCounters &tc) {
     float o[3] = {(float)ray.org.x, (float)ray.org.y, (float)ray.org.z};
     float d[3] = {(float)ray.dir.x, (float)ray.dir.y, (float)ray.dir.z};
     lc.rays++;
-    Hit h = closest_hit_ctx<WW>(sv, tx, o, d, (float)ray.tnear, (float)ray.tfar, tc);
+    Hit h = closest_hit_ctx<WW, WIDE>(sv, tx, o, d, (float)ray.tnear, (float)ray.tfar, tc);
     if (h.gid < 0) return false;
     make_vertex(sv, tx.tris, tx.need_uv, ray, h, 0.0, rd_spread, v);
     return true;
@@ -326,7 +358,7 @@ struct Lane {
 
 // SERIAL_RNG: one PCG stream runs through consecutive samples (TILE scheme); otherwise each sample owns stream
 // `base + s` (SAMPLE scheme) and its sub-pixel / bounce-1 numbers are re-derived from it when an offset needs them.
-template <bool LAMBERT, bool SERIAL_RNG, bool WW, class ACC>
+template <bool LAMBERT, bool SERIAL_RNG, bool WW, bool WIDE, class ACC>
 GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, double spp, int x, int y, unsigned long long base,
                   Lane &L, LanePriv &lp, ACC &acc, LaneCounters &lc, TraceCounters &tc) {
     const DevCamera &cam = sv.cam;
@@ -340,7 +372,7 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
     // ---------------- TRACE (uniform over the wave) ----------------
     const bool tracing = (st0 == S_PRIMARY || st0 == S_BOUNCE || st0 == S_OFFSET);
     bool hit = false;
-    if (tracing) hit = intersect_ctx<WW>(sv, tx, ray, (st0 == S_BOUNCE) ? 0.0 : 0.25 / (double)max(w, h), nv, lc, tc);   // src/ray.h:33-35, :564
+    if (tracing) hit = intersect_ctx<WW, WIDE>(sv, tx, ray, (st0 == S_BOUNCE) ? 0.0 : 0.25 / (double)max(w, h), nv, lc, tc);   // src/ray.h:33-35, :564
     // ---------------- consume the hit ----------------
     if (st0 == S_START) {
         act = ACT_PRIMARY_RAY;
@@ -520,29 +552,27 @@ GD void reduce_and_store(const KernelArgs &a, Accum &acc, int K, bool writer, in
     }
 }
 
-GD int lds_scene_bytes(const DevSceneView &sv) {
-    return sv.num_nodes * (int)sizeof(DevBvhNode) + sv.num_prims * (int)sizeof(DevPrim) + sv.num_tris * (int)sizeof(DevTriShade) +
-           sv.num_materials * (int)sizeof(GdptMaterial);
-}
-// Copies nodes, primitive records, the shading table and the materials into LDS (small scenes) and returns the
-// trace context of this lane.
-template <bool LDS_SCENE>
+// Copies nodes (BVH2 or wide form), primitive records, the shading table and the materials into LDS (small scenes)
+// and returns the trace context of this lane.
+template <bool LDS_SCENE, bool WIDE>
 GD TraceCtx setup_trace(const DevSceneView &sv, unsigned char *s_scene, int *s_stack, int tid, int nthreads, bool count) {
     TraceCtx tx;
     tx.count = count;
     tx.need_uv = !sv.all_textures_constant;
     tx.stack = s_stack + tid; tx.stride = nthreads;
     if (LDS_SCENE) {
-        const int nw = sv.num_nodes * (int)(sizeof(DevBvhNode) / 4), pw = sv.num_prims * (int)(sizeof(DevPrim) / 4);
+        const int nw = WIDE ? sv.num_nodes4 * (int)(sizeof(DevBvh4Node) / 4) : sv.num_nodes * (int)(sizeof(DevBvhNode) / 4);
+        const int pw = sv.num_prims * (int)(sizeof(DevPrim) / 4);
         const int tw = sv.num_tris * (int)(sizeof(DevTriShade) / 4), mw = sv.num_materials * (int)(sizeof(GdptMaterial) / 4);
         unsigned *dst = (unsigned *)s_scene;
-        const unsigned *s0 = (const unsigned *)sv.nodes, *s1 = (const unsigned *)sv.prims, *s2 = (const unsigned *)sv.tris, *s3 = (const unsigned *)sv.materials;
+        const unsigned *s0 = WIDE ? (const unsigned *)sv.nodes4 : (const unsigned *)sv.nodes;
+        const unsigned *s1 = (const unsigned *)sv.prims, *s2 = (const unsigned *)sv.tris, *s3 = (const unsigned *)sv.materials;
         for (int i = tid; i < nw; i += nthreads) dst[i] = s0[i];
         for (int i = tid; i < pw; i += nthreads) dst[nw + i] = s1[i];
         for (int i = tid; i < tw; i += nthreads) dst[nw + pw + i] = s2[i];
         for (int i = tid; i < mw; i += nthreads) dst[nw + pw + tw + i] = s3[i];
         __syncthreads();
-        tx.nodes = (const DevBvhNode *)s_scene; tx.nodes4 = nullptr;
+        tx.nodes = (const DevBvhNode *)s_scene; tx.nodes4 = (const DevBvh4Node *)s_scene;
         tx.prims = (const DevPrim *)(s_scene + (size_t)nw * 4);
         tx.tris = (const DevTriShade *)(s_scene + (size_t)(nw + pw) * 4);
         tx.materials = (const GdptMaterial *)(s_scene + (size_t)(nw + pw + tw) * 4);
@@ -581,15 +611,15 @@ GD void item_to_pixel(const KernelArgs &a, int W, long long item, int &x, int &y
 // that finishes early picks up the next item instead of idling behind the longest path of its wave. Per-item sums go
 // to `partials` ([15][items], one writer per slot) and are merged per pixel in chunk order by gdpt_reduce_partials,
 // so the result does not depend on which lane processed what, or when.
-template <bool LAMBERT, bool LDS_SCENE, int WPS>
-__global__ __launch_bounds__(kBlock, WPS) void gdpt_render_phases(DevSceneView sv, KernelArgs a) {
+template <bool LAMBERT, bool LDS_SCENE, bool WIDE>
+__global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv, KernelArgs a) {
     constexpr int kLevels = LDS_SCENE ? kLdsSceneLevels : GDPT_BVH_MAX_DEPTH;
     __shared__ int s_stack[kLevels * kBlock];
     __shared__ __attribute__((aligned(16))) unsigned char s_scene[LDS_SCENE ? kLdsSceneBytes : 16];
     __shared__ double s_acc[15 * kBlock];
     __shared__ double s_priv[kPrivDoubles * kBlock];
     const int tid = threadIdx.x;
-    TraceCtx tx = setup_trace<LDS_SCENE>(sv, s_scene, s_stack, tid, kBlock, a.count != 0);
+    TraceCtx tx = setup_trace<LDS_SCENE, WIDE>(sv, s_scene, s_stack, tid, kBlock, a.count != 0);
     const int W = sv.cam.width;
     const double spp = (double)a.spp;
     AccLds acc; acc.slot = s_acc + tid; acc.stride = kBlock;
@@ -647,7 +677,7 @@ __global__ __launch_bounds__(kBlock, WPS) void gdpt_render_phases(DevSceneView s
             q_next += (n_idle < avail) ? n_idle : avail;
         }
         if (!__any(L.st != S_DONE)) { if (exhausted) break; else continue; }
-        lane_step<LAMBERT, false, !LDS_SCENE>(sv, tx, a.max_depth, spp, x, y, base, L, lp, acc, lc, tc);
+        lane_step<LAMBERT, false, !LDS_SCENE, WIDE>(sv, tx, a.max_depth, spp, x, y, base, L, lp, acc, lc, tc);
     }
     flush_counters(a, lc, tc, a.count != 0);
 }
@@ -682,7 +712,7 @@ __global__ __launch_bounds__(64) void gdpt_render_tile_stream_phases(DevSceneVie
     __shared__ double s_priv[kPrivDoubles * 64];
     const int tid = threadIdx.x;
     const int tile = blockIdx.x * 64 + tid;
-    TraceCtx tx = setup_trace<false>(sv, nullptr, s_stack, tid, 64, a.count != 0);
+    TraceCtx tx = setup_trace<false, true>(sv, nullptr, s_stack, tid, 64, a.count != 0);
     LanePriv lp; lp.slot = s_priv + tid; lp.stride = 64;
     LaneCounters lc = {0, 0, 0};
     TraceCounters tc = {0, 0};
@@ -700,7 +730,7 @@ __global__ __launch_bounds__(64) void gdpt_render_tile_stream_phases(DevSceneVie
             for (int x = x0; x < x1; x++) {
                 AccReg acc; acc.init();
                 L.s = 0; L.s_end = a.spp; L.st = S_START;
-                while (L.st != S_DONE) lane_step<LAMBERT, true, true>(sv, tx, a.max_depth, spp, x, y, 0ull, L, lp, acc, lc, tc);
+                while (L.st != S_DONE) lane_step<LAMBERT, true, true, true>(sv, tx, a.max_depth, spp, x, y, 0ull, L, lp, acc, lc, tc);
                 Accum sum = acc.result();
                 reduce_and_store(a, sum, 1, true, x, y, W);
             }
@@ -732,7 +762,7 @@ GD void grad_sample_eager(const DevSceneView &sv, const TraceCtx &tx, int max_de
     Ray ray = sample_primary(cam, (x + rng_x) / w, (y + rng_y) / h);
     const double rd_spread = 0.25 / (double)max(w, h);
     Vertex vertex;
-    if (!intersect_ctx<true>(sv, tx, ray, rd_spread, vertex, lc, tc)) return;
+    if (!intersect_ctx<true, true>(sv, tx, ray, rd_spread, vertex, lc, tc)) return;
     Offset off[4];
     unsigned alive = 0;
 #pragma unroll 1
@@ -740,7 +770,7 @@ GD void grad_sample_eager(const DevSceneView &sv, const TraceCtx &tx, int max_de
         int ox = (k == 0) ? -1 : (k == 1 ? 1 : 0), oy = (k == 2) ? 1 : (k == 3 ? -1 : 0);
         Ray r = sample_primary(cam, ((x + ox) + rng_x) / w, ((y + oy) + rng_y) / h);
         Vertex ov;
-        bool ok = intersect_ctx<true>(sv, tx, r, rd_spread, ov, lc, tc);
+        bool ok = intersect_ctx<true, true>(sv, tx, r, rd_spread, ov, lc, tc);
         if (ok && ov.material_id == vertex.material_id) {
             alive |= 1u << k;
             off[k].v = ov; off[k].dir = r.dir; off[k].jacob = 1.0;
@@ -762,7 +792,7 @@ GD void grad_sample_eager(const DevSceneView &sv, const TraceCtx &tx, int max_de
         if (bs.eta != 0) eta_scale /= (bs.eta * bs.eta);
         Ray bsdf_ray; bsdf_ray.org = vertex.position; bsdf_ray.dir = dir_bsdf; bsdf_ray.tnear = sv.isect_eps; bsdf_ray.tfar = __builtin_huge_val();
         Vertex bsdf_vertex;
-        bool hit = intersect_ctx<true>(sv, tx, bsdf_ray, 0.0, bsdf_vertex, lc, tc);
+        bool hit = intersect_ctx<true, true>(sv, tx, bsdf_ray, 0.0, bsdf_vertex, lc, tc);
         if (alive) {
 #pragma unroll 1
             for (int k = 0; k < 4; k++)
@@ -825,7 +855,7 @@ GD void accumulate_eager(AccReg &a, const SampleOut &s, double spp, LaneCounters
 __global__ __launch_bounds__(kBlock) void gdpt_render_eager(DevSceneView sv, KernelArgs a) {
     __shared__ int s_stack[GDPT_BVH_MAX_DEPTH * kBlock];
     const int tid = threadIdx.x;
-    TraceCtx tx = setup_trace<false>(sv, nullptr, s_stack, tid, kBlock, a.count != 0);
+    TraceCtx tx = setup_trace<false, true>(sv, nullptr, s_stack, tid, kBlock, a.count != 0);
     const int K = 1 << a.log2k;
     const int c = tid & (K - 1), p = tid >> a.log2k;
     const int px = p % a.tile_w, py = p / a.tile_w;
@@ -855,7 +885,7 @@ __global__ __launch_bounds__(64) void gdpt_render_tile_stream_eager(DevSceneView
     __shared__ int s_stack[GDPT_BVH_MAX_DEPTH * 64];
     const int tid = threadIdx.x;
     const int tile = blockIdx.x * 64 + tid;
-    TraceCtx tx = setup_trace<false>(sv, nullptr, s_stack, tid, 64, a.count != 0);
+    TraceCtx tx = setup_trace<false, true>(sv, nullptr, s_stack, tid, 64, a.count != 0);
     LaneCounters lc = {0, 0, 0};
     TraceCounters tc = {0, 0};
     const int W = sv.cam.width, H = sv.cam.height;
@@ -886,9 +916,9 @@ __global__ __launch_bounds__(64) void gdpt_render_tile_stream_eager(DevSceneView
 
 namespace gdpt {
 // host launchers, one translation unit per kernel family (parallel compilation)
-void launch_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, int wps, hipStream_t stream);
+void launch_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lds_wide, hipStream_t stream);
 void launch_reduce_partials(const DevSceneView &sv, const gd::KernelArgs &a, hipStream_t stream);
-void launch_phases_general(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, hipStream_t stream);
+void launch_phases_general(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lds_wide, hipStream_t stream);
 void launch_tile_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
 void launch_tile_phases_general(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
 void launch_eager(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, hipStream_t stream);

@@ -24,13 +24,14 @@ struct RenderLaunch {
     bool force_eager;              // run the eager evaluator regardless (checks / A-B runs)
     int thresh_a, thresh_c;        // lanes that must wait for phase A / C before a wave runs it (0 = default)
     int force_log2k;               // lanes per pixel = 2^force_log2k (-1 = automatic)
-    int waves_per_simd;            // register budget variant of the phase kernel (2, 3 or 4)
+    bool lds_wide;                 // LDS-resident scene walked in its BVH4 form
     int num_cus;                   // compute units of the device (persistent grid size)
     int blocks_per_cu;             // persistent blocks per CU (0 = default 2)
     double *partials;              // device, >= 15 * W * rows * 8 doubles (work-item partial sums)
     unsigned long long *queue_head;// device, work-queue head
 };
 bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_materials, int bvh_depth);
+bool scene_fits_lds_wide(int num_nodes4, int num_prims, int num_tris, int num_materials, int wide_stack_need);
 
 // Doubles the `partials` buffer must hold for a band of `pixels` pixels at `spp`.
 size_t render_partials_doubles(long long pixels, int spp);

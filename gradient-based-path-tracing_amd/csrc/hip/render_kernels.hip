@@ -56,8 +56,8 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
             if (blocks > (waves_needed + 3) / 4) blocks = (waves_needed + 3) / 4;
             if (blocks < 1) blocks = 1;
             dim3 grid((unsigned)blocks);
-            if (rl.lambert_only) launch_phases_lambert(sv, a, grid, rl.scene_fits_lds, rl.waves_per_simd, stream);
-            else launch_phases_general(sv, a, grid, rl.scene_fits_lds, stream);
+            if (rl.lambert_only) launch_phases_lambert(sv, a, grid, rl.scene_fits_lds, rl.lds_wide, stream);
+            else launch_phases_general(sv, a, grid, rl.scene_fits_lds, rl.lds_wide, stream);
             launch_reduce_partials(sv, a, stream);
         }
     } else {
@@ -78,6 +78,12 @@ bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_material
     size_t bytes = (size_t)num_nodes * sizeof(DevBvhNode) + (size_t)num_prims * sizeof(DevPrim) +
                    (size_t)num_tris * sizeof(DevTriShade) + (size_t)num_materials * sizeof(GdptMaterial);
     return bytes <= (size_t)gd::kLdsSceneBytes && bvh_depth <= gd::kLdsSceneLevels && num_nodes > 0;
+}
+
+bool scene_fits_lds_wide(int num_nodes4, int num_prims, int num_tris, int num_materials, int wide_stack_need) {
+    size_t bytes = (size_t)num_nodes4 * sizeof(DevBvh4Node) + (size_t)num_prims * sizeof(DevPrim) +
+                   (size_t)num_tris * sizeof(DevTriShade) + (size_t)num_materials * sizeof(GdptMaterial);
+    return bytes <= (size_t)gd::kLdsSceneBytes && wide_stack_need <= gd::kLdsSceneLevels && num_nodes4 > 0;
 }
 
 } // namespace gdpt

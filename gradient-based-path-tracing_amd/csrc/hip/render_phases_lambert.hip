@@ -2,15 +2,10 @@
 #define GDPT_BUILD_REDUCE 1
 #include "render_device.h"
 namespace gdpt {
-template <int WPS>
-static void launch_wps(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, hipStream_t stream) {
-    if (lds) hipLaunchKernelGGL((gd::gdpt_render_phases<true, true, WPS>), grid, dim3(gd::kBlock), 0, stream, sv, a);
-    else hipLaunchKernelGGL((gd::gdpt_render_phases<true, false, WPS>), grid, dim3(gd::kBlock), 0, stream, sv, a);
-}
-void launch_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, int wps, hipStream_t stream) {
-    if (wps >= 4) launch_wps<4>(sv, a, grid, lds, stream);
-    else if (wps == 3) launch_wps<3>(sv, a, grid, lds, stream);
-    else launch_wps<2>(sv, a, grid, lds, stream);
+void launch_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lds_wide, hipStream_t stream) {
+    if (lds && lds_wide) hipLaunchKernelGGL((gd::gdpt_render_phases<true, true, true>), grid, dim3(gd::kBlock), 0, stream, sv, a);
+    else if (lds) hipLaunchKernelGGL((gd::gdpt_render_phases<true, true, false>), grid, dim3(gd::kBlock), 0, stream, sv, a);
+    else hipLaunchKernelGGL((gd::gdpt_render_phases<true, false, true>), grid, dim3(gd::kBlock), 0, stream, sv, a);
 }
 void launch_reduce_partials(const DevSceneView &sv, const gd::KernelArgs &a, hipStream_t stream) {
     const long long npix = a.num_items / a.chunks;

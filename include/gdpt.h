@@ -146,6 +146,7 @@ typedef struct GdptRenderStats {
     uint64_t tris_tested;      /* triangles tested (counting builds only, else 0) */
     uint64_t nonfinite_samples;/* samples whose record held a NaN/Inf (propagated, as the reference does) */
     double render_ms;          /* device time of the render kernel(s), HIP events */
+    uint64_t node_bytes;       /* size of one fetched BVH node in the form this render walked (64: BVH2, 128: BVH4) */
 } GdptRenderStats;
 
 typedef struct GdptPoissonStats {
@@ -159,7 +160,7 @@ typedef struct GdptPoissonStats {
  *     from the reference by its fp32-lambda quirk, ~3e-9).  DCT: direct solve, exact reference operator. */
 enum { GDPT_SOLVER_CG = 0, GDPT_SOLVER_DCT = 1 };
 
-typedef struct GdptScene GdptScene;   /* opaque: device-resident scene (BVH2, triangles, materials, textures) */
+typedef struct GdptScene GdptScene;   /* opaque: device-resident scene (BVH2 + BVH4, triangles, materials, textures) */
 
 /* ---- host-side scene ingest (Mitsuba-0.x XML subset) ---- */
 int gdpt_parse_scene(const char *xml_path, GdptSceneDesc **out_desc);
