@@ -66,7 +66,8 @@ class GdptRenderParams(C.Structure):
 class GdptRenderStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("bounces", C.c_uint64),
                 ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("nonfinite_samples", C.c_uint64),
-                ("render_ms", C.c_double), ("node_bytes", C.c_uint64)]
+                ("render_ms", C.c_double), ("node_bytes", C.c_uint64),
+                ("wave_node_trips", C.c_uint64), ("wave_leaf_trips", C.c_uint64), ("wave_steps", C.c_uint64), ("lane_steps", C.c_uint64)]
 
 
 class GdptPoissonStats(C.Structure):

@@ -328,6 +328,8 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
         stats->nonfinite_samples = sc->h_counters->nonfinite;
         stats->nodes_visited = sc->h_counters->nodes; stats->tris_tested = sc->h_counters->prims;
         stats->render_ms = ms;
+        stats->wave_node_trips = sc->h_counters->wave_node_trips; stats->wave_leaf_trips = sc->h_counters->wave_leaf_trips;
+        stats->wave_steps = sc->h_counters->wave_steps; stats->lane_steps = sc->h_counters->lane_steps;
         // only the persistent kernel over an LDS-resident scene can still walk the BVH2 form
         const bool lds_kernel = rl.one_sided_materials && !rl.force_eager && b.rng == GDPT_RNG_SAMPLE && rl.scene_fits_lds;
         stats->node_bytes = (lds_kernel && !rl.lds_wide) ? sizeof(DevBvhNode) : sizeof(DevBvh4Node);

@@ -12,7 +12,9 @@ namespace gd {
 
 struct Hit { float t, u, v, ngx, ngy, ngz; int gid; };   // gid < 0: miss
 
-struct TraceCounters { unsigned nodes, prims; };   // per lane; summed in 64 bits across the wave
+struct TraceCounters { unsigned nodes, prims, node_trips, leaf_trips, wave_steps, lane_steps; };   // per lane; summed in 64 bits across the wave
+// counting builds: one lane of the currently active set ticks a per-wave event
+GD bool wave_leader() { return (int)(threadIdx.x & 63) == __ffsll((unsigned long long)__ballot(1)) - 1; }
 
 // fp32 Moller-Trumbore, two-sided; every operation rounds once (no FMA contraction), sums left to right.
 // The CPU checker used by the tests restates exactly this arithmetic.

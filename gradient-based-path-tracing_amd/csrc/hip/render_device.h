@@ -169,7 +169,7 @@ GD void test_leaf(const DevSceneView &sv, const TraceCtx &tx, int cur, const flo
     const DevPrim p1 = tx.prims[first + min(1u, last)];
     const DevPrim p2 = tx.prims[first + min(2u, last)];
     const DevPrim p3 = tx.prims[first + last];
-    if (tx.count) tc.prims += last + 1u;
+    if (tx.count) { tc.prims += last + 1u; if (wave_leader()) tc.leaf_trips++; }
     test_prim(sv, p0, o, d, tnear, tfar, best);
     if (last >= 1u) test_prim(sv, p1, o, d, tnear, tfar, best);
     if (last >= 2u) test_prim(sv, p2, o, d, tnear, tfar, best);
@@ -195,7 +195,7 @@ GD Hit closest_hit_ctx(const DevSceneView &sv, const TraceCtx &tx, const float o
     if (!WW) {
         for (;;) {
             if (cur >= 0) {
-                if (tx.count) tc.nodes++;
+                if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
                 if (WIDE) {
                     WideVisit w;
                     visit_wide(tx.nodes4[cur], oi, inv, tnear, best.t, w);
@@ -230,7 +230,7 @@ GD Hit closest_hit_ctx(const DevSceneView &sv, const TraceCtx &tx, const float o
     bool done = false;
     for (;;) {
         while (cur >= 0 && !done) {
-            if (tx.count) tc.nodes++;
+            if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
             if (WIDE) {
                 WideVisit w;
                 visit_wide(tx.nodes4[cur], oi, inv, tnear, best.t, w);
@@ -524,12 +524,21 @@ GD unsigned long long wave_sum_u64(unsigned long long v) {
 GD void flush_counters(const KernelArgs &a, const LaneCounters &lc, const TraceCounters &tc, bool count) {
     unsigned r = wave_sum_u32(lc.rays), b = wave_sum_u32(lc.bounces), nf = wave_sum_u32(lc.nonfinite);
     unsigned long long nn = 0, np = 0;
-    if (count) { nn = wave_sum_u64((unsigned long long)tc.nodes); np = wave_sum_u64((unsigned long long)tc.prims); }
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (count) {
+        nn = wave_sum_u64((unsigned long long)tc.nodes); np = wave_sum_u64((unsigned long long)tc.prims);
+        t0 = wave_sum_u64((unsigned long long)tc.node_trips); t1 = wave_sum_u64((unsigned long long)tc.leaf_trips);
+        t2 = wave_sum_u64((unsigned long long)tc.wave_steps); t3 = wave_sum_u64((unsigned long long)tc.lane_steps);
+    }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&a.counters->rays, (unsigned long long)r);
         atomicAdd(&a.counters->bounces, (unsigned long long)b);
         if (nf) atomicAdd(&a.counters->nonfinite, (unsigned long long)nf);
-        if (count) { atomicAdd(&a.counters->nodes, nn); atomicAdd(&a.counters->prims, np); }
+        if (count) {
+            atomicAdd(&a.counters->nodes, nn); atomicAdd(&a.counters->prims, np);
+            atomicAdd(&a.counters->wave_node_trips, t0); atomicAdd(&a.counters->wave_leaf_trips, t1);
+            atomicAdd(&a.counters->wave_steps, t2); atomicAdd(&a.counters->lane_steps, t3);
+        }
     }
 }
 
@@ -626,7 +635,7 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
     acc.init();
     LanePriv lp; lp.slot = s_priv + tid; lp.stride = kBlock;
     LaneCounters lc = {0, 0, 0};
-    TraceCounters tc = {0, 0};
+    TraceCounters tc = {0, 0, 0, 0, 0, 0};
     Lane L;
     L.s = 0; L.s_end = 0; L.st = S_DONE;
     L.kc = 0; L.num_vertices = 0; L.mats = 0xFFFFFF; L.rng_state = 0; L.rng_inc = 1;
@@ -677,6 +686,7 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
             q_next += (n_idle < avail) ? n_idle : avail;
         }
         if (!__any(L.st != S_DONE)) { if (exhausted) break; else continue; }
+        if (tx.count) { if (L.st != S_DONE) tc.lane_steps++; if (wave_leader()) tc.wave_steps++; }
         lane_step<LAMBERT, false, !LDS_SCENE, WIDE>(sv, tx, a.max_depth, spp, x, y, base, L, lp, acc, lc, tc);
     }
     flush_counters(a, lc, tc, a.count != 0);
@@ -715,7 +725,7 @@ __global__ __launch_bounds__(64) void gdpt_render_tile_stream_phases(DevSceneVie
     TraceCtx tx = setup_trace<false, true>(sv, nullptr, s_stack, tid, 64, a.count != 0);
     LanePriv lp; lp.slot = s_priv + tid; lp.stride = 64;
     LaneCounters lc = {0, 0, 0};
-    TraceCounters tc = {0, 0};
+    TraceCounters tc = {0, 0, 0, 0, 0, 0};
     const int W = sv.cam.width, H = sv.cam.height;
     const double spp = (double)a.spp;
     if (tile < ntx * nty) {
@@ -865,7 +875,7 @@ __global__ __launch_bounds__(kBlock) void gdpt_render_eager(DevSceneView sv, Ker
     const bool valid = (x < W) && (y < a.row_end);
     AccReg acc; acc.init();
     LaneCounters lc = {0, 0, 0};
-    TraceCounters tc = {0, 0};
+    TraceCounters tc = {0, 0, 0, 0, 0, 0};
     if (valid) {
         const int s0 = (int)(((long long)c * a.spp) >> a.log2k), s1 = (int)(((long long)(c + 1) * a.spp) >> a.log2k);
         const unsigned long long base = ((unsigned long long)y * W + x) * (unsigned long long)a.spp;
@@ -887,7 +897,7 @@ __global__ __launch_bounds__(64) void gdpt_render_tile_stream_eager(DevSceneView
     const int tile = blockIdx.x * 64 + tid;
     TraceCtx tx = setup_trace<false, true>(sv, nullptr, s_stack, tid, 64, a.count != 0);
     LaneCounters lc = {0, 0, 0};
-    TraceCounters tc = {0, 0};
+    TraceCounters tc = {0, 0, 0, 0, 0, 0};
     const int W = sv.cam.width, H = sv.cam.height;
     if (tile < ntx * nty) {
         const int txi = tile % ntx, tyi = tile / ntx;

@@ -7,6 +7,7 @@ namespace gdpt {
 
 struct RenderCounters {            // device-resident, zeroed per render
     unsigned long long rays, bounces, nonfinite, nodes, prims;
+    unsigned long long wave_node_trips, wave_leaf_trips, wave_steps, lane_steps;   // counting builds: SIMT utilisation
 };
 
 struct RenderLaunch {

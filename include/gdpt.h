@@ -147,6 +147,11 @@ typedef struct GdptRenderStats {
     uint64_t nonfinite_samples;/* samples whose record held a NaN/Inf (propagated, as the reference does) */
     double render_ms;          /* device time of the render kernel(s), HIP events */
     uint64_t node_bytes;       /* size of one fetched BVH node in the form this render walked (64: BVH2, 128: BVH4) */
+    /* SIMT utilisation of the persistent kernel (counting builds only, else 0): loop trips counted once per wave */
+    uint64_t wave_node_trips;  /* node-visit trips;  nodes_visited / (64 * this) = lane utilisation of the box tests */
+    uint64_t wave_leaf_trips;  /* leaf-test trips */
+    uint64_t wave_steps;       /* lane-machine steps (one pending ray per live lane each) */
+    uint64_t lane_steps;       /* live lanes summed over those steps */
 } GdptRenderStats;
 
 typedef struct GdptPoissonStats {

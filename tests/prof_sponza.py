@@ -17,3 +17,5 @@ p = G._params(spp, G.RNG_SAMPLE, (0, 0))
 b = {k: np.zeros((720, 1280, 3)) for k in ("img", "cx0", "cy0", "cx1", "cy1")}
 G._check(G.lib().gdpt_render(sc.handle, C.byref(p), *[b[k].ctypes.data_as(C.POINTER(C.c_double)) for k in b], C.byref(cs)))
 print("nodes/ray", cs.nodes_visited / cs.rays, "prims/ray", cs.tris_tested / cs.rays, "counting ms", cs.render_ms)
+print("node-trip lane utilisation", cs.nodes_visited / max(1, 64 * cs.wave_node_trips), "node trips/ray-step", cs.wave_node_trips / max(1, cs.wave_steps),
+      "leaf trips/step", cs.wave_leaf_trips / max(1, cs.wave_steps), "lanes/step", cs.lane_steps / max(1, cs.wave_steps), "wave steps", cs.wave_steps)
