@@ -298,7 +298,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.scene_fits_lds = gdpt::scene_fits_lds(sc->view.num_nodes, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->bvh_depth);
     auto env_int = [](const char *name, int def) { const char *v = std::getenv(name); return v ? std::atoi(v) : def; };
     rl.force_eager = env_int("GDPT_FORCE_EAGER", 0) != 0;           // tuning / A-B knobs (undocumented defaults are the product path)
-    rl.thresh_a = env_int("GDPT_THRESH_A", 0); rl.thresh_c = env_int("GDPT_THRESH_C", 0);
+    rl.thresh_a = env_int("GDPT_KEEP_FRAC", -1); rl.thresh_c = env_int("GDPT_SEARCH_FRAC", -1);
     rl.force_log2k = env_int("GDPT_LOG2K", -1);
     rl.num_cus = sc->num_cus;
     rl.blocks_per_cu = env_int("GDPT_BLOCKS_PER_CU", 0);

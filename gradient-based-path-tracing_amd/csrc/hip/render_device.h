@@ -176,14 +176,53 @@ GD void test_leaf(const DevSceneView &sv, const TraceCtx &tx, int cur, const flo
     if (last >= 3u) test_prim(sv, p3, o, d, tnear, tfar, best);
 }
 
-// Closest hit (definition: device_trace.h). WIDE: walk the BVH4 form (half the dependent node fetches of the BVH2).
-// WW: "while-while" loop order — all lanes first walk inner nodes until each holds a leaf (or has finished), then the
-// leaves are intersected together (large scenes walked from HBM: +6 % on sponza) — vs. one node or leaf per trip
-// (scenes resident in LDS: +5 % on cbox).
+// Resumable closest-hit traversal (definition of "closest": device_trace.h). The walk's whole state is (cur, sp, best)
+// plus the lane's stack column in LDS, so a wave can leave the loop while some rays are unfinished, shade and re-arm the
+// lanes that are done, and come back: `stop_below` = number of unfinished rays at or below which the loop is left
+// (0 = run every ray to completion).
+// WIDE: walk the BVH4 form (half the dependent node fetches of the BVH2). WW: "while-while" loop order — all lanes
+// first walk inner nodes until each holds a leaf (or has finished), then the leaves are intersected together (scenes
+// walked from HBM) — vs. one node or leaf per trip (scenes resident in LDS).
+constexpr int kTravDone = INT32_MIN;      // cur: >= 0 inner node, < 0 leaf (~cur = first << 2 | count-1), kTravDone finished
+struct Trav { Hit best; int cur, sp; };
+GD void trav_init(const DevSceneView &sv, Trav &tv, double tfar) {
+    tv.best.gid = -1; tv.best.t = (float)tfar; tv.best.u = tv.best.v = 0; tv.best.ngx = tv.best.ngy = tv.best.ngz = 0;
+    tv.sp = 0; tv.cur = (sv.num_nodes == 0) ? kTravDone : 0;
+}
+GD void trav_pop(const TraceCtx &tx, int &cur, int &sp) {
+    if (sp > 0) { sp--; cur = tx.stack[sp * tx.stride]; } else cur = kTravDone;
+}
+template <bool WIDE>
+GD void trav_node(const TraceCtx &tx, const float oi[3], const float inv[3], float tnear, float tb, int &cur, int &sp) {
+    if (WIDE) {
+        WideVisit w;
+        visit_wide(tx.nodes4[cur], oi, inv, tnear, tb, w);
+        if (w.key[0] != kMissKey) {
+            if (w.key[3] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[3]); sp++; }
+            if (w.key[2] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[2]); sp++; }
+            if (w.key[1] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[1]); sp++; }
+            cur = wide_child(w, w.key[0]);
+        } else trav_pop(tx, cur, sp);
+    } else {
+        const DevBvhNode &n = tx.nodes[cur];
+        float tl, tr;
+        bool hl = (n.left != GDPT_CHILD_EMPTY) && box_hit(n.lmin, n.lmax, oi, inv, tnear, tb, tl);
+        bool hr = (n.right != GDPT_CHILD_EMPTY) && box_hit(n.rmin, n.rmax, oi, inv, tnear, tb, tr);
+        if (hl && hr) {
+            int nearc = n.left, farc = n.right;
+            if (tr < tl) { nearc = n.right; farc = n.left; }
+            tx.stack[sp * tx.stride] = farc; sp++;
+            cur = nearc;
+        } else if (hl) cur = n.left;
+        else if (hr) cur = n.right;
+        else trav_pop(tx, cur, sp);
+    }
+}
+// Called by the lanes whose ray is unfinished (tv.cur != kTravDone); the others of the wave sit it out.
 template <bool WW, bool WIDE>
-GD Hit closest_hit_ctx(const DevSceneView &sv, const TraceCtx &tx, const float o[3], const float d[3], float tnear, float tfar, TraceCounters &tc) {
-    Hit best; best.gid = -1; best.t = tfar; best.u = best.v = 0; best.ngx = best.ngy = best.ngz = 0;
-    if (sv.num_nodes == 0) return best;
+GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, float tnear, float tfar, Trav &tv, int stop_below, int search_frac, TraceCounters &tc) {
+    const float o[3] = {(float)org.x, (float)org.y, (float)org.z};
+    const float d[3] = {(float)dir.x, (float)dir.y, (float)dir.z};
     float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
     float oi[3] = {o[0] * inv[0], o[1] * inv[1], o[2] * inv[2]};
     // a zero direction component gives inv = inf and o*inv = inf or NaN: the slab then drops out of fmin/fmax only if
@@ -191,89 +230,47 @@ GD Hit closest_hit_ctx(const DevSceneView &sv, const TraceCtx &tx, const float o
     // coordinate or the other axes reject)
 #pragma unroll
     for (int k = 0; k < 3; k++) if (d[k] == 0.0f) { inv[k] = __builtin_nanf(""); oi[k] = __builtin_nanf(""); }
-    int sp = 0, cur = 0;
-    if (!WW) {
-        for (;;) {
-            if (cur >= 0) {
-                if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
-                if (WIDE) {
-                    WideVisit w;
-                    visit_wide(tx.nodes4[cur], oi, inv, tnear, best.t, w);
-                    if (w.key[0] != kMissKey) {
-                        if (w.key[3] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[3]); sp++; }
-                        if (w.key[2] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[2]); sp++; }
-                        if (w.key[1] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[1]); sp++; }
-                        cur = wide_child(w, w.key[0]);
-                        continue;
-                    }
-                } else {
-                    const DevBvhNode &n = tx.nodes[cur];
-                    float tb = best.t, tl, tr;
-                    bool hl = (n.left != GDPT_CHILD_EMPTY) && box_hit(n.lmin, n.lmax, oi, inv, tnear, tb, tl);
-                    bool hr = (n.right != GDPT_CHILD_EMPTY) && box_hit(n.rmin, n.rmax, oi, inv, tnear, tb, tr);
-                    if (hl && hr) {
-                        int nearc = n.left, farc = n.right;
-                        if (tr < tl) { nearc = n.right; farc = n.left; }
-                        tx.stack[sp * tx.stride] = farc; sp++;
-                        cur = nearc;
-                        continue;
-                    } else if (hl) { cur = n.left; continue; }
-                    else if (hr) { cur = n.right; continue; }
-                }
-            } else test_leaf(sv, tx, cur, o, d, tnear, tfar, best, tc);
-            if (sp == 0) break;
-            sp--;
-            cur = tx.stack[sp * tx.stride];
-        }
-        return best;
-    }
-    bool done = false;
+    int cur = tv.cur, sp = tv.sp;
+    Hit best = tv.best;
     for (;;) {
-        while (cur >= 0 && !done) {
-            if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
-            if (WIDE) {
-                WideVisit w;
-                visit_wide(tx.nodes4[cur], oi, inv, tnear, best.t, w);
-                if (w.key[0] != kMissKey) {
-                    if (w.key[3] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[3]); sp++; }
-                    if (w.key[2] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[2]); sp++; }
-                    if (w.key[1] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[1]); sp++; }
-                    cur = wide_child(w, w.key[0]);
-                } else if (sp > 0) { sp--; cur = tx.stack[sp * tx.stride]; }
-                else done = true;
-            } else {
-                const DevBvhNode &n = tx.nodes[cur];
-                float tb = best.t, tl, tr;
-                bool hl = (n.left != GDPT_CHILD_EMPTY) && box_hit(n.lmin, n.lmax, oi, inv, tnear, tb, tl);
-                bool hr = (n.right != GDPT_CHILD_EMPTY) && box_hit(n.rmin, n.rmax, oi, inv, tnear, tb, tr);
-                if (hl && hr) {
-                    int nearc = n.left, farc = n.right;
-                    if (tr < tl) { nearc = n.right; farc = n.left; }
-                    tx.stack[sp * tx.stride] = farc; sp++;
-                    cur = nearc;
-                } else if (hl) cur = n.left;
-                else if (hr) cur = n.right;
-                else if (sp > 0) { sp--; cur = tx.stack[sp * tx.stride]; }
-                else done = true;
+        const int live = __popcll(__ballot(cur != kTravDone));
+        if (live <= stop_below) break;
+        if (WW) {
+            // inner nodes until at most search_frac/256 of the live lanes are still looking for their next leaf
+            // (waiting for the last lane costs ~ln(64) mean search lengths); those lanes sit out the leaf tests.
+            const int few = (live * search_frac) >> 8;
+            for (;;) {
+                const bool searching = cur >= 0;
+                if (__popcll(__ballot(searching)) <= few) break;
+                if (searching) {
+                    if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
+                    trav_node<WIDE>(tx, oi, inv, tnear, best.t, cur, sp);
+                }
             }
+            if (cur < 0 && cur != kTravDone) {
+                test_leaf(sv, tx, cur, o, d, tnear, tfar, best, tc);
+                trav_pop(tx, cur, sp);
+            }
+        } else if (cur >= 0) {
+            if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
+            trav_node<WIDE>(tx, oi, inv, tnear, best.t, cur, sp);
+        } else if (cur != kTravDone) {
+            test_leaf(sv, tx, cur, o, d, tnear, tfar, best, tc);
+            trav_pop(tx, cur, sp);
         }
-        if (done) break;
-        test_leaf(sv, tx, cur, o, d, tnear, tfar, best, tc);
-        if (sp == 0) break;
-        sp--;
-        cur = tx.stack[sp * tx.stride];
     }
-    return best;
+    tv.cur = cur; tv.sp = sp; tv.best = best;
 }
 
+// One ray, start to finish (eager evaluator).
 template <bool WW, bool WIDE>
 GD bool intersect_ctx(const DevSceneView &sv, const TraceCtx &tx, const Ray &ray, double rd_spread, Vertex &v, LaneCounters &lc, TraceCounters &tc) {
-    float o[3] = {(float)ray.org.x, (float)ray.org.y, (float)ray.org.z};
-    float d[3] = {(float)ray.dir.x, (float)ray.dir.y, (float)ray.dir.z};
     lc.rays++;
-    Hit h = closest_hit_ctx<WW, WIDE>(sv, tx, o, d, (float)ray.tnear, (float)ray.tfar, tc);
-    if (h.gid < 0) return false;
-    make_vertex(sv, tx.tris, tx.need_uv, ray, h, 0.0, rd_spread, v);
+    Trav tv;
+    trav_init(sv, tv, ray.tfar);
+    if (tv.cur != kTravDone) trav_run<WW, WIDE>(sv, tx, ray.org, ray.dir, (float)ray.tnear, (float)ray.tfar, tv, 0, 0, tc);
+    if (tv.best.gid < 0) return false;
+    make_vertex(sv, tx.tris, tx.need_uv, ray, tv.best, 0.0, rd_spread, v);
     return true;
 }
 
@@ -360,7 +357,7 @@ struct Lane {
 // `base + s` (SAMPLE scheme) and its sub-pixel / bounce-1 numbers are re-derived from it when an offset needs them.
 template <bool LAMBERT, bool SERIAL_RNG, bool WW, bool WIDE, class ACC>
 GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, double spp, int x, int y, unsigned long long base,
-                  Lane &L, LanePriv &lp, ACC &acc, LaneCounters &lc, TraceCounters &tc) {
+                  Lane &L, Trav &tv, LanePriv &lp, ACC &acc, LaneCounters &lc, TraceCounters &tc) {
     const DevCamera &cam = sv.cam;
     const int w = cam.width, h = cam.height;
     const int st0 = L.st;
@@ -369,10 +366,14 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
     Ray ray;
     ray.org = L.org; ray.dir = L.dir; ray.tfar = __builtin_huge_val();
     ray.tnear = (st0 == S_BOUNCE) ? sv.isect_eps : 0.0;
-    // ---------------- TRACE (uniform over the wave) ----------------
+    // ---------------- the pending ray's traversal has finished (tv): rebuild the hit vertex ----------------
     const bool tracing = (st0 == S_PRIMARY || st0 == S_BOUNCE || st0 == S_OFFSET);
     bool hit = false;
-    if (tracing) hit = intersect_ctx<WW, WIDE>(sv, tx, ray, (st0 == S_BOUNCE) ? 0.0 : 0.25 / (double)max(w, h), nv, lc, tc);   // src/ray.h:33-35, :564
+    if (tracing) {
+        lc.rays++;
+        hit = tv.best.gid >= 0;
+        if (hit) make_vertex(sv, tx.tris, tx.need_uv, ray, tv.best, 0.0, (st0 == S_BOUNCE) ? 0.0 : 0.25 / (double)max(w, h), nv);   // src/ray.h:33-35, :564
+    }
     // ---------------- consume the hit ----------------
     if (st0 == S_START) {
         act = ACT_PRIMARY_RAY;
@@ -509,7 +510,22 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
         if (act == ACT_PRIMARY_RAY) lp.set_fc(fc);
         L.org = r.org; L.dir = r.dir;
     }
+    if (L.st != S_DONE) trav_init(sv, tv, __builtin_huge_val());      // every surviving lane now holds a fresh pending ray
 }
+
+// The lane machine's two halves. trace_pending: traversal of the wave's unfinished pending rays, left when at most
+// `keep_frac`/256 of them are still unfinished; step_ready: lane_step for the lanes whose ray is done (or that need a
+// first ray). Lanes still in flight keep (tv, stack) and continue on the next call.
+GD bool lane_tracing(int st) { return st == S_PRIMARY || st == S_BOUNCE || st == S_OFFSET; }
+template <bool WW, bool WIDE>
+GD void trace_pending(const DevSceneView &sv, const TraceCtx &tx, const Lane &L, Trav &tv, int keep_frac, int search_frac, TraceCounters &tc) {
+    const bool pending = lane_tracing(L.st) && tv.cur != kTravDone;
+    const unsigned long long m = __ballot(pending);
+    if (m == 0ull) return;
+    const int stop_below = (__popcll(m) * keep_frac) >> 8;
+    if (pending) trav_run<WW, WIDE>(sv, tx, L.org, L.dir, (L.st == S_BOUNCE) ? (float)sv.isect_eps : 0.0f, __builtin_huge_valf(), tv, stop_below, search_frac, tc);
+}
+GD bool lane_ready(const Lane &L, const Trav &tv) { return L.st == S_START || (lane_tracing(L.st) && tv.cur == kTravDone); }
 
 GD unsigned wave_sum_u32(unsigned v) {
 #pragma unroll
@@ -620,7 +636,7 @@ GD void item_to_pixel(const KernelArgs &a, int W, long long item, int &x, int &y
 // that finishes early picks up the next item instead of idling behind the longest path of its wave. Per-item sums go
 // to `partials` ([15][items], one writer per slot) and are merged per pixel in chunk order by gdpt_reduce_partials,
 // so the result does not depend on which lane processed what, or when.
-template <bool LAMBERT, bool LDS_SCENE, bool WIDE>
+template <bool LAMBERT, bool LDS_SCENE, bool WIDE, bool WW>
 __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv, KernelArgs a) {
     constexpr int kLevels = LDS_SCENE ? kLdsSceneLevels : GDPT_BVH_MAX_DEPTH;
     __shared__ int s_stack[kLevels * kBlock];
@@ -637,6 +653,8 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
     LaneCounters lc = {0, 0, 0};
     TraceCounters tc = {0, 0, 0, 0, 0, 0};
     Lane L;
+    Trav tv;
+    trav_init(sv, tv, __builtin_huge_val());
     L.s = 0; L.s_end = 0; L.st = S_DONE;
     L.kc = 0; L.num_vertices = 0; L.mats = 0xFFFFFF; L.rng_state = 0; L.rng_inc = 1;
     L.org = L.dir = splat(0);
@@ -686,8 +704,11 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
             q_next += (n_idle < avail) ? n_idle : avail;
         }
         if (!__any(L.st != S_DONE)) { if (exhausted) break; else continue; }
-        if (tx.count) { if (L.st != S_DONE) tc.lane_steps++; if (wave_leader()) tc.wave_steps++; }
-        lane_step<LAMBERT, false, !LDS_SCENE, WIDE>(sv, tx, a.max_depth, spp, x, y, base, L, lp, acc, lc, tc);
+        trace_pending<WW, WIDE>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
+        if (lane_ready(L, tv)) {
+            if (tx.count) { tc.lane_steps++; if (wave_leader()) tc.wave_steps++; }
+            lane_step<LAMBERT, false, WW, WIDE>(sv, tx, a.max_depth, spp, x, y, base, L, tv, lp, acc, lc, tc);
+        }
     }
     flush_counters(a, lc, tc, a.count != 0);
 }
@@ -734,13 +755,19 @@ __global__ __launch_bounds__(64) void gdpt_render_tile_stream_phases(DevSceneVie
         { Pcg r0 = pcg_init((unsigned long long)(tyi * ntx + txi)); L.rng_state = r0.state; L.rng_inc = r0.inc; }
         L.kc = 0; L.num_vertices = 0; L.mats = 0xFFFFFF;
         L.org = L.dir = splat(0);
+        Trav tv;
+        trav_init(sv, tv, __builtin_huge_val());
         const int x0 = txi * 16, x1 = min(x0 + 16, W), y0 = tyi * 16, y1 = min(y0 + 16, H);
         for (int y = y0; y < y1; y++) {
             if (y < a.row_begin || y >= a.row_end) continue;   // bands are whole tile rows in this mode
             for (int x = x0; x < x1; x++) {
                 AccReg acc; acc.init();
                 L.s = 0; L.s_end = a.spp; L.st = S_START;
-                while (L.st != S_DONE) lane_step<LAMBERT, true, true, true>(sv, tx, a.max_depth, spp, x, y, 0ull, L, lp, acc, lc, tc);
+                while (L.st != S_DONE) {
+                    if (lane_tracing(L.st) && tv.cur != kTravDone)
+                        trav_run<true, true>(sv, tx, L.org, L.dir, (L.st == S_BOUNCE) ? (float)sv.isect_eps : 0.0f, __builtin_huge_valf(), tv, 0, 0, tc);
+                    lane_step<LAMBERT, true, true, true>(sv, tx, a.max_depth, spp, x, y, 0ull, L, tv, lp, acc, lc, tc);
+                }
                 Accum sum = acc.result();
                 reduce_and_store(a, sum, 1, true, x, y, W);
             }

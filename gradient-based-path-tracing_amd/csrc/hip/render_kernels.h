@@ -23,7 +23,7 @@ struct RenderLaunch {
     bool lambert_only;             // every material is Lambertian
     bool scene_fits_lds;           // BVH nodes + primitive records fit the block's LDS copy
     bool force_eager;              // run the eager evaluator regardless (checks / A-B runs)
-    int thresh_a, thresh_c;        // lanes that must wait for phase A / C before a wave runs it (0 = default)
+    int thresh_a, thresh_c;        // trace-phase exit fractions /256 (unfinished rays; lanes still searching a leaf), -1 = default
     int force_log2k;               // lanes per pixel = 2^force_log2k (-1 = automatic)
     bool lds_wide;                 // LDS-resident scene walked in its BVH4 form
     int num_cus;                   // compute units of the device (persistent grid size)

@@ -14,8 +14,10 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
     gd::KernelArgs a{};
     a.spp = rl.spp; a.row_begin = rl.row_begin; a.row_end = rl.row_end; a.max_depth = rl.max_depth;
     a.img = rl.img; a.cx0 = rl.cx0; a.cy0 = rl.cy0; a.cx1 = rl.cx1; a.cy1 = rl.cy1; a.counters = rl.counters;
-    a.thresh_a = rl.thresh_a > 0 ? rl.thresh_a : 24;
-    a.thresh_c = rl.thresh_c > 0 ? rl.thresh_c : 24;
+    // trace phase is left when this fraction (/256) of the rays that entered it is still unfinished
+    a.thresh_a = rl.thresh_a >= 0 ? (rl.thresh_a > 255 ? 255 : rl.thresh_a) : 64;
+    // ... and its inner-node loop when this fraction of the live rays is still looking for the next leaf
+    a.thresh_c = rl.thresh_c >= 0 ? (rl.thresh_c > 255 ? 255 : rl.thresh_c) : 112;
     a.count = rl.count_traversal ? 1 : 0;
     const int W = sv.cam.width, rows = rl.row_end - rl.row_begin;
     if (W <= 0 || rows <= 0 || rl.spp <= 0) throw std::runtime_error("launch_render: empty image band or spp <= 0");

@@ -17,6 +17,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps(out))
 else:
     for kf in sys.argv[1:]:
-        env = dict(os.environ, GDPT_KEEP_FRAC=kf)
+        k, sf, ww = (kf.split(":") + ["0", "0"])[:3]
+        env = dict(os.environ, GDPT_KEEP_FRAC=k, GDPT_SEARCH_FRAC=sf, GDPT_LDS_WW=ww)
         r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
         print("keep_frac", kf, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:], flush=True)
