@@ -93,6 +93,30 @@ GD void test_prim(const DevSceneView &sv, const DevPrim &pr, const float o[3], c
     }
 }
 
+// The same test without control flow (the arithmetic of tri_hit, operation for operation): in a 64-wide wave some lane
+// passes every early-out anyway, so the branches only cost exec-mask bookkeeping. `valid`: the record belongs to the
+// lane's leaf. Rejections by NaN (det = 0 gives inv = inf) fall out of the comparisons exactly as in tri_hit.
+GD void test_tri_flat(const DevPrim &tr, const float o[3], const float d[3], float tnear, float tfar, bool valid, Hit &best) {
+#pragma clang fp contract(off)
+    const float *e1 = tr.e1, *e2 = tr.e2;
+    float px = d[1] * e2[2] - d[2] * e2[1];
+    float py = d[2] * e2[0] - d[0] * e2[2];
+    float pz = d[0] * e2[1] - d[1] * e2[0];
+    float det = e1[0] * px + e1[1] * py + e1[2] * pz;
+    float inv = 1.0f / det;
+    float sx = o[0] - tr.v0[0], sy = o[1] - tr.v0[1], sz = o[2] - tr.v0[2];
+    float u = (sx * px + sy * py + sz * pz) * inv;
+    float qx = sy * e1[2] - sz * e1[1];
+    float qy = sz * e1[0] - sx * e1[2];
+    float qz = sx * e1[1] - sy * e1[0];
+    float v = (d[0] * qx + d[1] * qy + d[2] * qz) * inv;
+    float t = (e2[0] * qx + e2[1] * qy + e2[2] * qz) * inv;
+    const int gid = (int)tr.gid;
+    bool ok = valid & (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t >= tnear) & (t < tfar);
+    ok = ok & ((best.gid < 0) | (t < best.t) | ((t == best.t) & (gid < best.gid)));
+    best.t = ok ? t : best.t; best.u = ok ? u : best.u; best.v = ok ? v : best.v; best.gid = ok ? gid : best.gid;
+}
+
 // Slab test against boxes the host has already widened (gdpt_scene_upload pads every child box by 1e-6 of the scene
 // extent). Distances are formed as fma(bound, 1/d, -o/d): the cancellation error of that form is at most
 // 2^-24 |o| |1/d|, an eighth of the padding's 1e-6 extent |1/d|; the remaining relative error of the products is

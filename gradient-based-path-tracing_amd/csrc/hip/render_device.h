@@ -138,11 +138,14 @@ struct TraceCtx {
 
 // One BVH4 node: tests the four child boxes and returns the hit children sorted near to far. key = entry distance
 // (>= 0, so its bit pattern orders like the float) with the child slot in the low two bits; 0xFFFFFFFF = missed.
-struct WideVisit { unsigned key[4]; int c0, c1, c2, c3; };
+struct WideVisit { unsigned key[4]; int ch[4]; };    // ch[i]: child behind key[i]
 constexpr unsigned kMissKey = 0xFFFFFFFFu;
-GD int wide_child(const WideVisit &w, unsigned k) { const unsigned c = k & 3u; return c == 0 ? w.c0 : (c == 1 ? w.c1 : (c == 2 ? w.c2 : w.c3)); }
+GD int pick4(unsigned k, int a0, int a1, int a2, int a3) {     // three v_cndmask, no branches
+    const int lo = (k & 1u) ? a1 : a0, hi = (k & 1u) ? a3 : a2;
+    return (k & 2u) ? hi : lo;
+}
 GD void visit_wide(const DevBvh4Node &n, const float oi[3], const float inv[3], float tnear, float tb, WideVisit &w) {
-    w.c0 = n.child[0]; w.c1 = n.child[1]; w.c2 = n.child[2]; w.c3 = n.child[3];
+    const int c0 = n.child[0], c1 = n.child[1], c2 = n.child[2], c3 = n.child[3];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         float t0 = tnear, t1 = tb;
@@ -157,10 +160,13 @@ GD void visit_wide(const DevBvh4Node &n, const float oi[3], const float inv[3], 
 #define GDPT_CSWAP(i, j) { unsigned lo_ = min(w.key[i], w.key[j]), hi_ = max(w.key[i], w.key[j]); w.key[i] = lo_; w.key[j] = hi_; }
     GDPT_CSWAP(0, 1) GDPT_CSWAP(2, 3) GDPT_CSWAP(0, 2) GDPT_CSWAP(1, 3) GDPT_CSWAP(1, 2)
 #undef GDPT_CSWAP
+#pragma unroll
+    for (int i = 0; i < 4; i++) w.ch[i] = pick4(w.key[i], c0, c1, c2, c3);
 }
 
 // A leaf holds 1..4 primitive records. All of them are fetched before the first test (indices clamped to the leaf, so
 // short leaves re-read their last record): the leaf then costs one memory latency instead of one per primitive.
+template <bool FLAT>
 GD void test_leaf(const DevSceneView &sv, const TraceCtx &tx, int cur, const float o[3], const float d[3], float tnear, float tfar,
                   Hit &best, TraceCounters &tc) {
     const unsigned packed = ~(unsigned)cur;
@@ -170,10 +176,19 @@ GD void test_leaf(const DevSceneView &sv, const TraceCtx &tx, int cur, const flo
     const DevPrim p2 = tx.prims[first + min(2u, last)];
     const DevPrim p3 = tx.prims[first + last];
     if (tx.count) { tc.prims += last + 1u; if (wave_leader()) tc.leaf_trips++; }
-    test_prim(sv, p0, o, d, tnear, tfar, best);
-    if (last >= 1u) test_prim(sv, p1, o, d, tnear, tfar, best);
-    if (last >= 2u) test_prim(sv, p2, o, d, tnear, tfar, best);
-    if (last >= 3u) test_prim(sv, p3, o, d, tnear, tfar, best);
+    // FLAT (scenes walked from HBM, incoherent rays): four branch-free triangle tests. Otherwise (small LDS-resident
+    // scenes, where whole waves miss a triangle together) the early-outs of tri_hit pay.
+    if (!FLAT || ((p0.gid | p1.gid | p2.gid | p3.gid) & GDPT_SPHERE_FLAG)) {     // (a sphere in the leaf: general test)
+        test_prim(sv, p0, o, d, tnear, tfar, best);
+        if (last >= 1u) test_prim(sv, p1, o, d, tnear, tfar, best);
+        if (last >= 2u) test_prim(sv, p2, o, d, tnear, tfar, best);
+        if (last >= 3u) test_prim(sv, p3, o, d, tnear, tfar, best);
+    } else {
+        test_tri_flat(p0, o, d, tnear, tfar, true, best);
+        test_tri_flat(p1, o, d, tnear, tfar, last >= 1u, best);
+        test_tri_flat(p2, o, d, tnear, tfar, last >= 2u, best);
+        test_tri_flat(p3, o, d, tnear, tfar, last >= 3u, best);
+    }
 }
 
 // Resumable closest-hit traversal (definition of "closest": device_trace.h). The walk's whole state is (cur, sp, best)
@@ -198,10 +213,10 @@ GD void trav_node(const TraceCtx &tx, const float oi[3], const float inv[3], flo
         WideVisit w;
         visit_wide(tx.nodes4[cur], oi, inv, tnear, tb, w);
         if (w.key[0] != kMissKey) {
-            if (w.key[3] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[3]); sp++; }
-            if (w.key[2] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[2]); sp++; }
-            if (w.key[1] != kMissKey) { tx.stack[sp * tx.stride] = wide_child(w, w.key[1]); sp++; }
-            cur = wide_child(w, w.key[0]);
+            if (w.key[3] != kMissKey) { tx.stack[sp * tx.stride] = w.ch[3]; sp++; }
+            if (w.key[2] != kMissKey) { tx.stack[sp * tx.stride] = w.ch[2]; sp++; }
+            if (w.key[1] != kMissKey) { tx.stack[sp * tx.stride] = w.ch[1]; sp++; }
+            cur = w.ch[0];
         } else trav_pop(tx, cur, sp);
     } else {
         const DevBvhNode &n = tx.nodes[cur];
@@ -218,8 +233,12 @@ GD void trav_node(const TraceCtx &tx, const float oi[3], const float inv[3], flo
         else trav_pop(tx, cur, sp);
     }
 }
+// Compile-time traversal configuration of a kernel: loop order, tree form, leaf test style.
+template <bool WW_, bool WIDE_, bool FLAT_> struct TraceCfg { static constexpr bool WW = WW_, WIDE = WIDE_, FLAT = FLAT_; };
+using TraceHbm = TraceCfg<true, true, true>;       // scenes walked from HBM
+
 // Called by the lanes whose ray is unfinished (tv.cur != kTravDone); the others of the wave sit it out.
-template <bool WW, bool WIDE>
+template <class TC>
 GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, float tnear, float tfar, Trav &tv, int stop_below, int search_frac, TraceCounters &tc) {
     const float o[3] = {(float)org.x, (float)org.y, (float)org.z};
     const float d[3] = {(float)dir.x, (float)dir.y, (float)dir.z};
@@ -235,7 +254,7 @@ GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, flo
     for (;;) {
         const int live = __popcll(__ballot(cur != kTravDone));
         if (live <= stop_below) break;
-        if (WW) {
+        if (TC::WW) {
             // inner nodes until at most search_frac/256 of the live lanes are still looking for their next leaf
             // (waiting for the last lane costs ~ln(64) mean search lengths); those lanes sit out the leaf tests.
             const int few = (live * search_frac) >> 8;
@@ -244,18 +263,18 @@ GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, flo
                 if (__popcll(__ballot(searching)) <= few) break;
                 if (searching) {
                     if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
-                    trav_node<WIDE>(tx, oi, inv, tnear, best.t, cur, sp);
+                    trav_node<TC::WIDE>(tx, oi, inv, tnear, best.t, cur, sp);
                 }
             }
             if (cur < 0 && cur != kTravDone) {
-                test_leaf(sv, tx, cur, o, d, tnear, tfar, best, tc);
+                test_leaf<TC::FLAT>(sv, tx, cur, o, d, tnear, tfar, best, tc);
                 trav_pop(tx, cur, sp);
             }
         } else if (cur >= 0) {
             if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
-            trav_node<WIDE>(tx, oi, inv, tnear, best.t, cur, sp);
+            trav_node<TC::WIDE>(tx, oi, inv, tnear, best.t, cur, sp);
         } else if (cur != kTravDone) {
-            test_leaf(sv, tx, cur, o, d, tnear, tfar, best, tc);
+            test_leaf<TC::FLAT>(sv, tx, cur, o, d, tnear, tfar, best, tc);
             trav_pop(tx, cur, sp);
         }
     }
@@ -263,12 +282,12 @@ GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, flo
 }
 
 // One ray, start to finish (eager evaluator).
-template <bool WW, bool WIDE>
+template <class TC>
 GD bool intersect_ctx(const DevSceneView &sv, const TraceCtx &tx, const Ray &ray, double rd_spread, Vertex &v, LaneCounters &lc, TraceCounters &tc) {
     lc.rays++;
     Trav tv;
     trav_init(sv, tv, ray.tfar);
-    if (tv.cur != kTravDone) trav_run<WW, WIDE>(sv, tx, ray.org, ray.dir, (float)ray.tnear, (float)ray.tfar, tv, 0, 0, tc);
+    if (tv.cur != kTravDone) trav_run<TC>(sv, tx, ray.org, ray.dir, (float)ray.tnear, (float)ray.tfar, tv, 0, 0, tc);
     if (tv.best.gid < 0) return false;
     make_vertex(sv, tx.tris, tx.need_uv, ray, tv.best, 0.0, rd_spread, v);
     return true;
@@ -355,7 +374,7 @@ struct Lane {
 
 // SERIAL_RNG: one PCG stream runs through consecutive samples (TILE scheme); otherwise each sample owns stream
 // `base + s` (SAMPLE scheme) and its sub-pixel / bounce-1 numbers are re-derived from it when an offset needs them.
-template <bool LAMBERT, bool SERIAL_RNG, bool WW, bool WIDE, class ACC>
+template <bool LAMBERT, bool SERIAL_RNG, class ACC>
 GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, double spp, int x, int y, unsigned long long base,
                   Lane &L, Trav &tv, LanePriv &lp, ACC &acc, LaneCounters &lc, TraceCounters &tc) {
     const DevCamera &cam = sv.cam;
@@ -517,13 +536,13 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
 // `keep_frac`/256 of them are still unfinished; step_ready: lane_step for the lanes whose ray is done (or that need a
 // first ray). Lanes still in flight keep (tv, stack) and continue on the next call.
 GD bool lane_tracing(int st) { return st == S_PRIMARY || st == S_BOUNCE || st == S_OFFSET; }
-template <bool WW, bool WIDE>
+template <class TC>
 GD void trace_pending(const DevSceneView &sv, const TraceCtx &tx, const Lane &L, Trav &tv, int keep_frac, int search_frac, TraceCounters &tc) {
     const bool pending = lane_tracing(L.st) && tv.cur != kTravDone;
     const unsigned long long m = __ballot(pending);
     if (m == 0ull) return;
     const int stop_below = (__popcll(m) * keep_frac) >> 8;
-    if (pending) trav_run<WW, WIDE>(sv, tx, L.org, L.dir, (L.st == S_BOUNCE) ? (float)sv.isect_eps : 0.0f, __builtin_huge_valf(), tv, stop_below, search_frac, tc);
+    if (pending) trav_run<TC>(sv, tx, L.org, L.dir, (L.st == S_BOUNCE) ? (float)sv.isect_eps : 0.0f, __builtin_huge_valf(), tv, stop_below, search_frac, tc);
 }
 GD bool lane_ready(const Lane &L, const Trav &tv) { return L.st == S_START || (lane_tracing(L.st) && tv.cur == kTravDone); }
 
@@ -704,10 +723,10 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
             q_next += (n_idle < avail) ? n_idle : avail;
         }
         if (!__any(L.st != S_DONE)) { if (exhausted) break; else continue; }
-        trace_pending<WW, WIDE>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
+        trace_pending<TraceCfg<WW, WIDE, !LDS_SCENE>>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
         if (lane_ready(L, tv)) {
             if (tx.count) { tc.lane_steps++; if (wave_leader()) tc.wave_steps++; }
-            lane_step<LAMBERT, false, WW, WIDE>(sv, tx, a.max_depth, spp, x, y, base, L, tv, lp, acc, lc, tc);
+            lane_step<LAMBERT, false>(sv, tx, a.max_depth, spp, x, y, base, L, tv, lp, acc, lc, tc);
         }
     }
     flush_counters(a, lc, tc, a.count != 0);
@@ -765,8 +784,8 @@ __global__ __launch_bounds__(64) void gdpt_render_tile_stream_phases(DevSceneVie
                 L.s = 0; L.s_end = a.spp; L.st = S_START;
                 while (L.st != S_DONE) {
                     if (lane_tracing(L.st) && tv.cur != kTravDone)
-                        trav_run<true, true>(sv, tx, L.org, L.dir, (L.st == S_BOUNCE) ? (float)sv.isect_eps : 0.0f, __builtin_huge_valf(), tv, 0, 0, tc);
-                    lane_step<LAMBERT, true, true, true>(sv, tx, a.max_depth, spp, x, y, 0ull, L, tv, lp, acc, lc, tc);
+                        trav_run<TraceHbm>(sv, tx, L.org, L.dir, (L.st == S_BOUNCE) ? (float)sv.isect_eps : 0.0f, __builtin_huge_valf(), tv, 0, 0, tc);
+                    lane_step<LAMBERT, true>(sv, tx, a.max_depth, spp, x, y, 0ull, L, tv, lp, acc, lc, tc);
                 }
                 Accum sum = acc.result();
                 reduce_and_store(a, sum, 1, true, x, y, W);
@@ -799,7 +818,7 @@ GD void grad_sample_eager(const DevSceneView &sv, const TraceCtx &tx, int max_de
     Ray ray = sample_primary(cam, (x + rng_x) / w, (y + rng_y) / h);
     const double rd_spread = 0.25 / (double)max(w, h);
     Vertex vertex;
-    if (!intersect_ctx<true, true>(sv, tx, ray, rd_spread, vertex, lc, tc)) return;
+    if (!intersect_ctx<TraceHbm>(sv, tx, ray, rd_spread, vertex, lc, tc)) return;
     Offset off[4];
     unsigned alive = 0;
 #pragma unroll 1
@@ -807,7 +826,7 @@ GD void grad_sample_eager(const DevSceneView &sv, const TraceCtx &tx, int max_de
         int ox = (k == 0) ? -1 : (k == 1 ? 1 : 0), oy = (k == 2) ? 1 : (k == 3 ? -1 : 0);
         Ray r = sample_primary(cam, ((x + ox) + rng_x) / w, ((y + oy) + rng_y) / h);
         Vertex ov;
-        bool ok = intersect_ctx<true, true>(sv, tx, r, rd_spread, ov, lc, tc);
+        bool ok = intersect_ctx<TraceHbm>(sv, tx, r, rd_spread, ov, lc, tc);
         if (ok && ov.material_id == vertex.material_id) {
             alive |= 1u << k;
             off[k].v = ov; off[k].dir = r.dir; off[k].jacob = 1.0;
@@ -829,7 +848,7 @@ GD void grad_sample_eager(const DevSceneView &sv, const TraceCtx &tx, int max_de
         if (bs.eta != 0) eta_scale /= (bs.eta * bs.eta);
         Ray bsdf_ray; bsdf_ray.org = vertex.position; bsdf_ray.dir = dir_bsdf; bsdf_ray.tnear = sv.isect_eps; bsdf_ray.tfar = __builtin_huge_val();
         Vertex bsdf_vertex;
-        bool hit = intersect_ctx<true, true>(sv, tx, bsdf_ray, 0.0, bsdf_vertex, lc, tc);
+        bool hit = intersect_ctx<TraceHbm>(sv, tx, bsdf_ray, 0.0, bsdf_vertex, lc, tc);
         if (alive) {
 #pragma unroll 1
             for (int k = 0; k < 4; k++)
