@@ -170,6 +170,10 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
         float ext = 0.f;
         for (int k = 0; k < 3; k++) if (ub[k] >= lb[k]) ext = std::max(ext, std::max(std::fabs(ub[k]), std::fabs(lb[k])));
         for (auto &sp : spheres) for (int k = 0; k < 3; k++) ext = std::max(ext, (float)(std::fabs(sp.center[k]) + sp.radius));
+        {   // ray origins: surface points (inside the bounds) and the camera position, xform_point(cam_to_world, 0)
+            const double *m = cam.cam_to_world;
+            for (int k = 0; k < 3; k++) ext = std::max(ext, (float)std::fabs(m[4 * k + 3] / m[15]) * 1.0000002f);
+        }
         const float pad = ext * 1e-6f + 1e-30f;
         for (auto &n : bvh.nodes)
             for (int k = 0; k < 3; k++) {

@@ -117,10 +117,13 @@ GD void test_tri_flat(const DevPrim &tr, const float o[3], const float d[3], flo
     best.t = ok ? t : best.t; best.u = ok ? u : best.u; best.v = ok ? v : best.v; best.gid = ok ? gid : best.gid;
 }
 
-// Slab test against boxes the host has already widened (gdpt_scene_upload pads every child box by 1e-6 of the scene
-// extent). Distances are formed as fma(bound, 1/d, -o/d): the cancellation error of that form is at most
-// 2^-24 |o| |1/d|, an eighth of the padding's 1e-6 extent |1/d|; the remaining relative error of the products is
-// absorbed by the 1e-6 slack on the exit distance. Never rejects a box holding a primitive that can report t <= tbest.
+// Slab test against boxes the host has already widened (gdpt_scene_upload pads every child box by P = 1e-6 E, E = the
+// largest absolute coordinate of the scene bounds and the camera position, i.e. of every possible ray origin).
+// Distances are formed as fma(bound, 1/d, -o/d). With e = 2^-24: 1/d and o/d round once each and the fma once, so a
+// computed distance is off by at most e (2|t| + |o/d|) = e (2|bound-o| + |o|)/|d| <= 5 e E/|d| = 3e-7 E/|d|, less than
+// the P/|d| by which the padding moved the plane. The computed interval therefore always contains the true interval
+// of the unpadded box, and no relative slack is needed: a box holding a primitive that reports t <= tbest is never
+// rejected. Axes with d = 0 (or 1/d overflowing) produce NaN and drop out of fmin/fmax.
 GD bool box_hit(const float *mn, const float *mx, const float oi[3], const float inv[3], float tnear, float tbest, float &tin) {
     float t0 = tnear, t1 = tbest;
 #pragma unroll
@@ -129,7 +132,7 @@ GD bool box_hit(const float *mn, const float *mx, const float oi[3], const float
         t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));       // NaN (inf - inf, 0*inf) is dropped by fmin/fmax
     }
     tin = t0;
-    return t0 <= t1 * 1.000001f;
+    return t0 <= t1;
 }
 
 // ---- intersect() post-processing: src/intersection.cpp:37-63 + compute_shading_info ----------------
