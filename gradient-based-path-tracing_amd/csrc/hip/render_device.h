@@ -146,25 +146,12 @@ GD int pick4(unsigned k, int a0, int a1, int a2, int a3) {     // three v_cndmas
 }
 GD void visit_wide(const DevBvh4Node &n, const float oi[3], const float inv[3], float tnear, float tb, WideVisit &w) {
     const int c0 = n.child[0], c1 = n.child[1], c2 = n.child[2], c3 = n.child[3];
-    // plane distances two children at a time (v_pk_fma_f32), then per-child interval
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 ta[3][2], tb2[3][2];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const f2 iv = {inv[k], inv[k]}, no = {-oi[k], -oi[k]};
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const f2 lo = {n.lo[k][2 * h], n.lo[k][2 * h + 1]}, hi = {n.hi[k][2 * h], n.hi[k][2 * h + 1]};
-            ta[k][h] = __builtin_elementwise_fma(lo, iv, no);
-            tb2[k][h] = __builtin_elementwise_fma(hi, iv, no);
-        }
-    }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         float t0 = tnear, t1 = tb;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const float a = ta[k][c >> 1][c & 1], b = tb2[k][c >> 1][c & 1];
+            float a = fmaf(n.lo[k][c], inv[k], -oi[k]), b = fmaf(n.hi[k][c], inv[k], -oi[k]);
             t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));       // NaN (inf - inf, 0*inf) is dropped by fmin/fmax
         }
         const int ch = c == 0 ? c0 : (c == 1 ? c1 : (c == 2 ? c2 : c3));
