@@ -307,7 +307,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.num_cus = sc->num_cus;
     rl.blocks_per_cu = env_int("GDPT_BLOCKS_PER_CU", 0);
     {
-        size_t need = gdpt::render_partials_doubles((long long)sc->view.cam.width * (b.row_end - b.row_begin), b.spp);
+        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, b.spp, rl.force_log2k);
         if (need > sc->partials_doubles) {
             if (sc->d_partials) { ck(hipStreamSynchronize(stream), "hipStreamSynchronize"); hipFree(sc->d_partials); sc->d_partials = nullptr; }
             ck(hipMalloc((void **)&sc->d_partials, need * sizeof(double)), "hipMalloc(work-item partials)");

@@ -47,8 +47,8 @@ struct KernelArgs {
     int spp, log2k, tile_w, tile_h, tiles_x;
     int row_begin, row_end, max_depth;
     int thresh_a, thresh_c;
-    int count, chunks;                 // chunks: work items per pixel
-    long long num_items;               // pixels in the band * chunks
+    int count, log2c;                  // 2^log2c work items (chunks of the sample range) per pixel
+    long long num_items;               // tiles of the band * 256 * chunks (< 2^32)
     double *partials;                  // [15][num_items]
     unsigned long long *queue_head;    // work-queue head (zeroed per launch)
     double *img, *cx0, *cy0, *cx1, *cy1;
@@ -627,28 +627,17 @@ GD TraceCtx setup_trace(const DevSceneView &sv, unsigned char *s_scene, int *s_s
     return tx;
 }
 
-// Work items of the persistent kernel: item = pixel_index * C + chunk, pixels enumerated tile by tile (16x16, the
-// reference's tile shape) inside the band so that a wave's batch of 64 consecutive items covers neighbouring pixels.
-GD void item_to_pixel(const KernelArgs &a, int W, long long item, int &x, int &y, int &s0, int &s1) {
-    const int C = a.chunks;
-    const long long p = item / C;
-    const int c = (int)(item - p * C);
-    const int tiles_x = (W + 15) >> 4;
-    const int rows = a.row_end - a.row_begin;
-    // pixels of full tile rows: 16 * W each (ragged right tiles are narrower, so walk tile rows explicitly)
-    const long long per_tile_row = (long long)16 * W;
-    const int trow = (int)(p / per_tile_row);
-    long long q = p - (long long)trow * per_tile_row;
-    const int th = min(16, rows - trow * 16);          // height of this tile row (last one may be short)
-    // inside a tile row: tiles left to right, each tile th x tw pixels in row-major order
-    const long long full_tile = (long long)16 * th;
-    int tcol = (int)(q / full_tile);
-    if (tcol >= tiles_x) tcol = tiles_x - 1;
-    q -= (long long)tcol * full_tile;
-    const int tw = min(16, W - tcol * 16);
-    const int py = (int)(q / tw), px = (int)(q - (long long)py * tw);
-    x = tcol * 16 + px; y = a.row_begin + trow * 16 + py;
-    s0 = (int)(((long long)c * a.spp) / C); s1 = (int)(((long long)(c + 1) * a.spp) / C);
+// Work items of the persistent kernel: item = ((tile * 256 + pixel_in_tile) << log2c) + chunk, tiles = the reference's
+// 16x16 tiles of the band in row-major order (ragged edge tiles keep all 256 slots; their outside pixels are empty
+// items), so a wave's batch of 64 consecutive items covers neighbouring pixels and the mapping needs one 32-bit
+// division. Returns false for an empty slot.
+GD bool item_to_pixel(const KernelArgs &a, int W, unsigned item, int &x, int &y, int &s0, int &s1) {
+    const unsigned c = item & ((1u << a.log2c) - 1u), pt = item >> a.log2c;
+    const unsigned pin = pt & 255u, tile = pt >> 8;
+    const unsigned ty = tile / (unsigned)a.tiles_x, tx = tile - ty * (unsigned)a.tiles_x;
+    x = (int)(tx * 16u + (pin & 15u)); y = a.row_begin + (int)(ty * 16u + (pin >> 4));
+    s0 = (int)(((long long)c * a.spp) >> a.log2c); s1 = (int)(((long long)(c + 1u) * a.spp) >> a.log2c);
+    return x < W && y < a.row_end;
 }
 
 // SAMPLE stream, persistent threads. Every lane repeatedly takes a work item (pixel, chunk of the pixel's samples)
@@ -682,7 +671,7 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
     unsigned long long base = 0;
     long long my_item = -1;
     // wave-local slice of the queue (uniform across the wave)
-    long long q_next = 0, q_end = 0;
+    long long q_next = 0, q_end = 0, seen_head = 0;
     bool exhausted = false;
     const unsigned long long lane_lt = (1ull << (tid & 63)) - 1ull;
     for (;;) {
@@ -702,12 +691,19 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
         }
         const unsigned long long m_idle = __ballot(idle);
         if (m_idle) {
-            if (q_next >= q_end && !exhausted) {        // refill the wave's slice: one atomic per 64 items
+            if (q_next >= q_end && !exhausted) {        // refill the wave's slice with one atomic
+                // 64 items while plenty are left; towards the end only what the idle lanes (and a fair share of the
+                // remainder) can start now, so that no wave sits on unstarted items while others have run dry
+                const long long left = a.num_items - seen_head;
+                long long want = left / ((long long)gridDim.x * (kBlock / 64) * 4);
+                const long long n_idle_now = __popcll(m_idle);
+                want = want > 64 ? 64 : (want < n_idle_now ? n_idle_now : want);
                 unsigned long long got = 0;
-                if ((tid & 63) == 0) got = atomicAdd(a.queue_head, 64ull);
+                if ((tid & 63) == 0) got = atomicAdd(a.queue_head, (unsigned long long)want);
                 got = __shfl(got, 0, 64);
                 q_next = (long long)got;
-                q_end = min((long long)got + 64, a.num_items);
+                q_end = min((long long)got + want, a.num_items);
+                seen_head = q_end;
                 if (q_next >= a.num_items) { exhausted = true; q_end = q_next; }
             }
             const int avail = (int)(q_end - q_next);
@@ -715,10 +711,10 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
             if (idle && rank < avail) {
                 my_item = q_next + rank;
                 int s0, s1;
-                item_to_pixel(a, W, my_item, x, y, s0, s1);
+                const bool inside = item_to_pixel(a, W, (unsigned)my_item, x, y, s0, s1);
                 base = ((unsigned long long)y * W + x) * (unsigned long long)a.spp;
                 L.s = s0; L.s_end = s1;
-                L.st = (s0 < s1) ? S_START : S_DONE;
+                L.st = (inside && s0 < s1) ? S_START : S_DONE;
             }
             const int n_idle = __popcll(m_idle);
             q_next += (n_idle < avail) ? n_idle : avail;
@@ -736,20 +732,21 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
 #ifdef GDPT_BUILD_REDUCE   // emitted by render_phases_lambert.hip only (non-template kernel)
 // Sums the C per-chunk partials of every pixel in chunk order and writes the five images (one thread per pixel).
 __global__ __launch_bounds__(256) void gdpt_reduce_partials(KernelArgs a, int W) {
-    const long long npix = a.num_items / a.chunks;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // pixel index in item order
-    if (idx >= npix) return;
+    const long long nslots = a.num_items >> a.log2c;                     // pixel slots (tiles * 256)
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // pixel slot in item order
+    if (idx >= nslots) return;
     int x, y, s0, s1;
-    item_to_pixel(a, W, idx * a.chunks, x, y, s0, s1);
+    if (!item_to_pixel(a, W, (unsigned)(idx << a.log2c), x, y, s0, s1)) return;
     const size_t o = ((size_t)y * W + x) * 3;
+    const int chunks = 1 << a.log2c;
     double *img[5] = {a.img, a.cx0, a.cy0, a.cx1, a.cy1};
 #pragma unroll
     for (int b = 0; b < 5; b++)
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            const double *src = a.partials + (size_t)(b * 3 + ch) * a.num_items + idx * a.chunks;
+            const double *src = a.partials + (size_t)(b * 3 + ch) * a.num_items + (idx << a.log2c);
             double v = 0;
-            for (int c = 0; c < a.chunks; c++) v += src[c];
+            for (int c = 0; c < chunks; c++) v += src[c];
             img[b][o + ch] = v;
         }
 }

@@ -43,12 +43,12 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
             int tiles_y = (rows + a.tile_h - 1) / a.tile_h;
             launch_eager(sv, a, dim3((unsigned)(a.tiles_x * tiles_y)), stream);
         } else {
-            // persistent lanes pulling (pixel, chunk) items: ~4 samples per item, at most 8 items per pixel
-            int chunks = rl.spp / 4;
-            chunks = chunks < 1 ? 1 : (chunks > 8 ? 8 : chunks);
-            if (rl.force_log2k >= 0) { chunks = 1 << rl.force_log2k; if (chunks > rl.spp) chunks = rl.spp; }
-            a.chunks = chunks;
-            a.num_items = (long long)W * rows * chunks;
+            // persistent lanes pulling (pixel, chunk) items: >= 4 samples per item, at most 8 items per pixel
+            a.log2c = render_log2_chunks(rl.spp, rl.force_log2k);
+            a.tiles_x = (W + 15) / 16;
+            const long long tiles = (long long)a.tiles_x * ((rows + 15) / 16);
+            a.num_items = (tiles * 256) << a.log2c;
+            if (a.num_items >= (1LL << 32)) throw std::runtime_error("launch_render: image band too large for the 32-bit work queue");
             a.partials = rl.partials; a.queue_head = rl.queue_head;
             if (!a.partials || !a.queue_head) throw std::runtime_error("launch_render: work-queue buffers missing");
             hipError_t me = hipMemsetAsync(a.queue_head, 0, sizeof(unsigned long long), stream);
@@ -69,11 +69,16 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
     if (e != hipSuccess) throw std::runtime_error(std::string("render kernel launch failed: ") + hipGetErrorString(e));
 }
 
-size_t render_partials_doubles(long long pixels, int spp) {
-    int chunks = spp / 4;
-    chunks = chunks < 1 ? 1 : (chunks > 8 ? 8 : chunks);
-    if (chunks < 8) chunks = 8;   // room for the GDPT_LOG2K override
-    return (size_t)15 * (size_t)pixels * (size_t)chunks;
+int render_log2_chunks(int spp, int force_log2k) {
+    int log2c = 0;
+    while (log2c < 3 && (8 << log2c) <= spp) log2c++;          // 2^log2c <= spp/4, at most 8
+    if (force_log2k >= 0) { log2c = force_log2k; while (log2c > 0 && (1 << log2c) > spp) log2c--; }
+    return log2c;
+}
+
+size_t render_partials_doubles(int width, int rows, int spp, int force_log2k) {
+    const long long tiles = (long long)((width + 15) / 16) * ((rows + 15) / 16);
+    return (size_t)15 * (size_t)((tiles * 256) << render_log2_chunks(spp, force_log2k));
 }
 
 bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_materials, int bvh_depth) {
