@@ -49,7 +49,7 @@ struct KernelArgs {
     int thresh_a, thresh_c;
     int count, log2c;                  // 2^log2c work items (chunks of the sample range) per pixel
     long long num_items;               // tiles of the band * 256 * chunks (< 2^32)
-    double *partials;                  // [15][num_items]
+    double *partials;                  // [num_items][16]: 15 sums (r, dx0, dy0, dx1, dy1 as xyz) + pad, 128-B records
     unsigned long long *queue_head;    // work-queue head (zeroed per launch)
     double *img, *cx0, *cy0, *cx1, *cy1;
     gdpt::RenderCounters *counters;
@@ -679,13 +679,11 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
         const bool idle = (L.st == S_DONE);
         if (idle && my_item >= 0) {                     // item finished: publish its 15 sums, clear the slot
             Accum r = acc.result();
-            double *dst = a.partials + my_item;
-            const long long n = a.num_items;
-            dst[0] = r.r.x; dst[n] = r.r.y; dst[2 * n] = r.r.z;
-            dst[3 * n] = r.dx0.x; dst[4 * n] = r.dx0.y; dst[5 * n] = r.dx0.z;
-            dst[6 * n] = r.dy0.x; dst[7 * n] = r.dy0.y; dst[8 * n] = r.dy0.z;
-            dst[9 * n] = r.dx1.x; dst[10 * n] = r.dx1.y; dst[11 * n] = r.dx1.z;
-            dst[12 * n] = r.dy1.x; dst[13 * n] = r.dy1.y; dst[14 * n] = r.dy1.z;
+            // one 128-byte record per item (15 sums + pad), written as eight 16-byte stores: a single HBM line
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            d2 *dst = (d2 *)(a.partials + (size_t)my_item * 16);
+            dst[0] = d2{r.r.x, r.r.y}; dst[1] = d2{r.r.z, r.dx0.x}; dst[2] = d2{r.dx0.y, r.dx0.z}; dst[3] = d2{r.dy0.x, r.dy0.y};
+            dst[4] = d2{r.dy0.z, r.dx1.x}; dst[5] = d2{r.dx1.y, r.dx1.z}; dst[6] = d2{r.dy1.x, r.dy1.y}; dst[7] = d2{r.dy1.z, 0.0};
             acc.init();
             my_item = -1;
         }
@@ -732,23 +730,20 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
 #ifdef GDPT_BUILD_REDUCE   // emitted by render_phases_lambert.hip only (non-template kernel)
 // Sums the C per-chunk partials of every pixel in chunk order and writes the five images (one thread per pixel).
 __global__ __launch_bounds__(256) void gdpt_reduce_partials(KernelArgs a, int W) {
+    // 16 consecutive threads per pixel slot: thread j sums component j of the slot's 2^log2c records in chunk order
     const long long nslots = a.num_items >> a.log2c;                     // pixel slots (tiles * 256)
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // pixel slot in item order
-    if (idx >= nslots) return;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long idx = t >> 4;                                        // pixel slot in item order
+    const int j = (int)(t & 15);
+    if (idx >= nslots || j == 15) return;
     int x, y, s0, s1;
     if (!item_to_pixel(a, W, (unsigned)(idx << a.log2c), x, y, s0, s1)) return;
-    const size_t o = ((size_t)y * W + x) * 3;
     const int chunks = 1 << a.log2c;
-    double *img[5] = {a.img, a.cx0, a.cy0, a.cx1, a.cy1};
-#pragma unroll
-    for (int b = 0; b < 5; b++)
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            const double *src = a.partials + (size_t)(b * 3 + ch) * a.num_items + (idx << a.log2c);
-            double v = 0;
-            for (int c = 0; c < chunks; c++) v += src[c];
-            img[b][o + ch] = v;
-        }
+    const double *src = a.partials + ((size_t)(idx << a.log2c)) * 16 + j;
+    double v = 0;
+    for (int c = 0; c < chunks; c++) v += src[(size_t)c * 16];
+    double *img = (j < 3) ? a.img : (j < 6) ? a.cx0 : (j < 9) ? a.cy0 : (j < 12) ? a.cx1 : a.cy1;
+    img[((size_t)y * W + x) * 3 + (j % 3)] = v;
 }
 #endif // GDPT_BUILD_REDUCE
 

@@ -78,7 +78,7 @@ int render_log2_chunks(int spp, int force_log2k) {
 
 size_t render_partials_doubles(int width, int rows, int spp, int force_log2k) {
     const long long tiles = (long long)((width + 15) / 16) * ((rows + 15) / 16);
-    return (size_t)15 * (size_t)((tiles * 256) << render_log2_chunks(spp, force_log2k));
+    return (size_t)16 * (size_t)((tiles * 256) << render_log2_chunks(spp, force_log2k));
 }
 
 bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_materials, int bvh_depth) {

@@ -9,7 +9,7 @@ void launch_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3
 }
 void launch_reduce_partials(const DevSceneView &sv, const gd::KernelArgs &a, hipStream_t stream) {
     const long long nslots = a.num_items >> a.log2c;
-    hipLaunchKernelGGL(gd::gdpt_reduce_partials, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, stream, a, sv.cam.width);
+    hipLaunchKernelGGL(gd::gdpt_reduce_partials, dim3((unsigned)((nslots * 16 + 255) / 256)), dim3(256), 0, stream, a, sv.cam.width);
 }
 void launch_tile_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream) {
     hipLaunchKernelGGL((gd::gdpt_render_tile_stream_phases<true>), grid, dim3(64), 0, stream, sv, a, ntx, nty);
