@@ -83,13 +83,16 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     ptr = lambda t: t.data_ptr()
 
+    gather_scratch = {}
+
     def step(want_stats=False):
         rs = scene.render_device([ptr(bufs[k]) for k in names], spp=spp_total, rng_scheme=G.RNG_SAMPLE,
                                  rows=(r0, r1), stream=stream, want_stats=want_stats)
-        if world > 1:
-            for k in names:      # the one exchange step of the path: gather the five accumulation buffers (RCCL over xGMI)
-                sharding.gather_bands(dist, bufs[k], H, world, rank)
+        if world > 1:            # exchange step 1: the last cy1 row of the band above (W*24 bytes, point to point)
+            sharding.halo_exchange_cy1(dist, bufs["cy1"], H, world, rank)
         G.assemble_device(W, H, [ptr(bufs[k]) for k in names], [ptr(c), ptr(cx), ptr(cy)], stream=stream)
+        if world > 1:            # exchange step 2: ONE packed all-gather of the assembled bands (RCCL over xGMI)
+            sharding.gather_packed(dist, [c, cx, cy], H, world, rank, gather_scratch)
         ps = G.poisson_solve_device(W, H, ptr(c), ptr(cx), ptr(cy), ptr(out), alpha=args.alpha, stream=stream,
                                     want_stats=want_stats)
         return rs, ps
@@ -158,7 +161,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"scenes/cbox/cbox_gdpt.xml Integrator::GradPath {W}x{H}, {args.spp} spp per GPU "
                                f"({spp_total} spp total), render+assemble+Poisson(DCT-I as fp64 GEMM) per step",
-                   "rng": "sample-stream PCG32", "sharding": f"{world} row band(s) + all-gather" if world > 1 else "single GPU",
+                   "rng": "sample-stream PCG32", "sharding": f"{world} row bands, 1-row halo + one packed all-gather of c,cx,cy" if world > 1 else "single GPU",
                    "alpha": args.alpha},
         "render_ms": render_ms_avg, "render_msamples_per_s": samples_rank / render_ms_avg / 1e3 if render_ms_avg > 0 else 0.0,
         "poisson_ms": poisson_ms_avg, "poisson_iterations": iters,

@@ -3,8 +3,13 @@ precedes the global Poisson solve.
 
 The reference parallelises gradient_path_render over 16x16 tiles only (src/render.cpp:271-277); a tile's result
 depends on nothing but the read-only scene and its RNG streams, so contiguous bands of whole tile rows go to
-ranks. The only exchange step of the path is gathering the five accumulation buffers before
-gradient assembly (cy needs cy1 of the row above, src/render.cpp:348-349) and the global solve.
+ranks. The exchange step of the path sits between the render and the global solve. Two forms:
+
+  * gather_bands: all-gather of an accumulation buffer (five of them, then assembly everywhere);
+  * halo_then_gather (what bench.py uses): with row bands cx = cx0(x,y) + cx1(x-1,y) is band-local and
+    cy = cy0(x,y) + cy1(x,y-1) needs only the last cy1 row of the band above (src/render.cpp:345-349), so each rank
+    receives that one row from its predecessor (W*24 bytes, point to point), assembles c, cx, cy for its own band,
+    and ONE packed all-gather moves the three assembled images (3/5 of the bytes, 1 collective instead of 5).
 Backend-agnostic: works with torch.distributed over RCCL ("nccl") on GPUs and over gloo on CPU tensors (tests).
 """
 
@@ -48,3 +53,63 @@ def gather_bands(dist, buf, height, world, rank):
             if b[1] > b[0]:
                 buf[b[0]:b[1]] = p[:(b[1] - b[0]) * row_elems].view(b[1] - b[0], buf.shape[1], buf.shape[2])
     return buf
+
+
+def equal_bands(height, world):
+    """True when every rank owns the same, non-zero number of rows (the packed single-collective path applies)."""
+    bands = all_bands(height, world)
+    sizes = {b[1] - b[0] for b in bands}
+    return len(sizes) == 1 and bands[-1][1] == height and bands[0][1] > bands[0][0]
+
+
+def halo_exchange_cy1(dist, cy1, height, world, rank):
+    """Row r0-1 of `cy1` (HxWx3) is filled with the last row of the band above (owned by rank-1); this rank's last
+    row goes to rank+1. Point-to-point, W*3 values each way."""
+    if world == 1:
+        return cy1
+    bands = all_bands(height, world)
+    r0, r1 = bands[rank]
+    ops, recv_row = [], None
+    # neighbours by band adjacency (skip ranks that own nothing)
+    owners = [r for r in range(world) if bands[r][1] > bands[r][0]]
+    if r1 > r0:
+        i = owners.index(rank)
+        if i + 1 < len(owners):
+            ops.append(dist.P2POp(dist.isend, cy1[r1 - 1].contiguous(), owners[i + 1]))
+        if i > 0:
+            recv_row = cy1.new_empty(cy1[r0 - 1].shape)
+            ops.append(dist.P2POp(dist.irecv, recv_row, owners[i - 1]))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if recv_row is not None:
+        cy1[r0 - 1].copy_(recv_row)
+    return cy1
+
+
+def gather_packed(dist, images, height, world, rank, scratch=None):
+    """In-place all-gather of several HxWx3 images whose rows [r0,r1) are valid on this rank, as ONE collective when
+    the bands are equal (falls back to gather_bands per image otherwise). `scratch`: optional dict reused across calls
+    for the packed send/receive buffers."""
+    if world == 1:
+        return images
+    if not equal_bands(height, world):
+        for im in images:
+            gather_bands(dist, im, height, world, rank)
+        return images
+    r0, r1 = band_rows(height, world, rank)
+    n = len(images)
+    band_elems = (r1 - r0) * images[0].shape[1] * images[0].shape[2]
+    scratch = {} if scratch is None else scratch
+    key = (n, band_elems, images[0].dtype, images[0].device)
+    if scratch.get("key") != key:
+        scratch["key"] = key
+        scratch["send"] = images[0].new_empty((n, band_elems))
+        scratch["recv"] = images[0].new_empty((world, n, band_elems))
+    send, recv = scratch["send"], scratch["recv"]
+    for i, im in enumerate(images):
+        send[i].copy_(im[r0:r1].reshape(-1))
+    dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
+    for i, im in enumerate(images):      # [world][band] of image i is the image itself (bands are rank-ordered)
+        im.view(world, band_elems).copy_(recv[:, i])
+    return images

@@ -76,3 +76,55 @@ def test_band_rows_cover_the_image_in_whole_tile_rows(G):
                 assert r0 % 16 == 0 and (r1 % 16 == 0 or r1 == h) and r0 <= r1
             sizes = [(b[1] - b[0] + 15) // 16 for b in bands]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _assemble_np(img, cx0, cy0, cx1, cy1):
+    """src/render.cpp:340-350 in numpy (c = img, cx = cx0 + cx1 shifted right, cy = cy0 + cy1 shifted down)."""
+    cx = cx0.copy(); cx[:, 1:] += cx1[:, :-1]
+    cy = cy0.copy(); cy[1:] += cy1[:-1]
+    return img.copy(), cx, cy
+
+
+def _halo_worker(rank, world, port, height, width, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gdpt_amd import sharding
+    rng = np.random.default_rng(5)
+    full = {k: rng.standard_normal((height, width, 3)) for k in ("img", "cx0", "cy0", "cx1", "cy1")}
+    r0, r1 = sharding.band_rows(height, world, rank)
+    mine = {}
+    for k, v in full.items():          # this rank only knows its own band; everything else is poison
+        t = torch.full((height, width, 3), -7.0, dtype=torch.float64)
+        t[r0:r1] = torch.from_numpy(v[r0:r1])
+        mine[k] = t
+    sharding.halo_exchange_cy1(dist, mine["cy1"], height, world, rank)
+    c, cx, cy = _assemble_np(*[mine[k].numpy() for k in ("img", "cx0", "cy0", "cx1", "cy1")])
+    parts = [torch.from_numpy(a.copy()) for a in (c, cx, cy)]
+    for t in parts:                     # rows outside the band were assembled from poison: poison them again
+        t[:r0] = -9.0
+        t[r1:] = -9.0
+    scratch = {}
+    for _ in range(2):                  # second call reuses the scratch buffers
+        sharding.gather_packed(dist, parts, height, world, rank, scratch)
+    np.savez(os.path.join(out_dir, f"halo{rank}.npz"), c=parts[0].numpy(), cx=parts[1].numpy(), cy=parts[2].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,height", [(2, 64), (4, 64), (3, 80), (3, 32)])
+def test_halo_exchange_and_packed_gather_match_global_assembly(tmp_path, world, height):
+    """One cy1 row from the band above + local assembly + one packed all-gather == assembling the whole image
+    (equal bands use the single collective; (3,80) is ragged and (3,32) leaves a rank without rows)."""
+    width = 24
+    rng = np.random.default_rng(5)
+    full = {k: rng.standard_normal((height, width, 3)) for k in ("img", "cx0", "cy0", "cx1", "cy1")}
+    want = _assemble_np(*[full[k] for k in ("img", "cx0", "cy0", "cx1", "cy1")])
+    port = _free_port()
+    mp.spawn(_halo_worker, args=(world, port, height, width, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = np.load(tmp_path / f"halo{r}.npz")
+        for name, w in zip(("c", "cx", "cy"), want):
+            assert np.array_equal(got[name], w), (r, name)
