@@ -62,6 +62,8 @@ def lib():
         L.gdpt_gradient_path_render.argtypes = [vp, C.POINTER(defs.GdptRenderParams), C.c_double, dp, dp, dp, dp, dp, dp,
                                                 C.POINTER(defs.GdptRenderStats), C.POINTER(defs.GdptPoissonStats)]
         L.gdpt_imwrite.argtypes = [C.c_char_p, C.c_int, C.c_int, dp]
+        L.gdpt_imread.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(dp)]
+        L.gdpt_image_free.argtypes = [dp]
         L.gdpt_bvh_check.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int32)]
         _LIB = L
     return _LIB
@@ -211,6 +213,18 @@ def imwrite(filename, image):
     img = np.ascontiguousarray(image, dtype=np.float64)
     h, w, _ = img.shape
     _check(lib().gdpt_imwrite(os.fsencode(filename), w, h, _dp(img)))
+
+
+def imread(filename, channels=3):
+    """imread3 / imread1 of the reference (src/image.cpp:26-133): HxWxC float64 texels."""
+    w, h = C.c_int(), C.c_int()
+    p = C.POINTER(C.c_double)()
+    _check(lib().gdpt_imread(os.fsencode(filename), int(channels), C.byref(w), C.byref(h), C.byref(p)))
+    try:
+        a = np.ctypeslib.as_array(p, shape=(h.value, w.value, int(channels))).copy()
+    finally:
+        lib().gdpt_image_free(p)
+    return a
 
 
 def bvh_check(bounds):

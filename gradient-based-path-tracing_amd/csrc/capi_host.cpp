@@ -6,6 +6,7 @@
 #include "host/scene_loader.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <algorithm>
@@ -49,6 +50,20 @@ int gdpt_imwrite(const char *filename, int width, int height, const double *rgb)
         gdpt::write_image(filename, width, height, rgb);
     });
 }
+
+int gdpt_imread(const char *filename, int channels, int *width, int *height, double **texels) {
+    return gdpt::guarded([&]() {
+        if (!filename || !width || !height || !texels || (channels != 1 && channels != 3)) throw std::runtime_error("gdpt_imread: bad argument");
+        std::vector<double> t;
+        gdpt::load_texture_file(filename, channels, width, height, &t);
+        double *out = (double *)std::malloc(t.size() * sizeof(double));
+        if (!out) throw std::runtime_error("gdpt_imread: out of memory");
+        std::memcpy(out, t.data(), t.size() * sizeof(double));
+        *texels = out;
+    });
+}
+
+void gdpt_image_free(double *texels) { std::free(texels); }
 
 int gdpt_bvh_check(const float *bounds6, int n, int32_t stats[8]) {
     return gdpt::guarded([&]() {

@@ -1,9 +1,13 @@
 // image_io.cpp — see image_io.h. Own writers (the reference vendors tinyexr/stb_image).
 #include "image_io.h"
+#include "jpeg_decode.h"
 
 #include <zlib.h>
 
+#include <algorithm>
+#include <cctype>
 #include <cmath>
+#include <iterator>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -18,27 +22,31 @@ bool ends_with(const std::string &s, const std::string &suf) {
     return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
 }
 
-// IEEE binary32 -> binary16, round to nearest even, overflow to inf, NaN kept.
+// binary32 -> binary16 the way the reference's writer does it (tinyexr's conversion behind SaveEXR,
+// src/3rdparty/tinyexr.h:889-924): the first dropped mantissa bit alone decides the rounding (ties go away from
+// zero, not to even), a carry may run into the exponent (up to infinity), float subnormals flush to signed zero,
+// NaN becomes the quiet NaN 0x7E00 pattern.
 uint16_t float_to_half(float f) {
     uint32_t x;
     std::memcpy(&x, &f, 4);
-    uint32_t sign = (x >> 16) & 0x8000u;
-    uint32_t em = x & 0x7FFFFFFFu;
-    if (em >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | (em > 0x7F800000u ? 0x200u | ((em >> 13) & 0x3FFu) : 0u));
-    if (em >= 0x47800000u) return (uint16_t)(sign | 0x7C00u);             // >= 65536 -> inf (values rounding up to it handled below)
-    if (em < 0x33000001u) return (uint16_t)sign;                           // < 2^-25 rounds to zero
-    int exp = (int)(em >> 23) - 127;
-    uint32_t man = (em & 0x7FFFFFu) | 0x800000u;
-    int shift;
-    uint32_t hexp;
-    if (exp < -14) { shift = 13 + (-14 - exp); hexp = 0; } else { shift = 13; hexp = (uint32_t)(exp + 15); }
-    uint32_t half_man = man >> shift;
-    uint32_t rem = man & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
-    if (rem > halfway || (rem == halfway && (half_man & 1u))) half_man++;
-    uint32_t h;
-    if (hexp == 0) h = half_man;                       // subnormal (may carry into exponent 1 naturally)
-    else h = ((hexp << 10) + (half_man - 0x400u));     // carry propagates into the exponent
-    if (h >= 0x7C00u) h = 0x7C00u;
+    const uint32_t sign = (x >> 16) & 0x8000u, e = (x >> 23) & 0xFFu, m = x & 0x7FFFFFu;
+    uint32_t h = 0;
+    if (e == 0) h = 0;
+    else if (e == 255) h = 0x7C00u | (m ? 0x200u : 0u);
+    else {
+        const int ne = (int)e - 127 + 15;
+        if (ne >= 31) h = 0x7C00u;
+        else if (ne <= 0) {
+            if (14 - ne <= 24) {
+                const uint32_t mant = m | 0x800000u;
+                h = mant >> (14 - ne);
+                if ((mant >> (13 - ne)) & 1u) h++;
+            }
+        } else {
+            h = ((uint32_t)ne << 10) | (m >> 13);
+            if (m & 0x1000u) h++;
+        }
+    }
     return (uint16_t)(sign | h);
 }
 
@@ -50,7 +58,73 @@ void attr(std::vector<unsigned char> &b, const char *name, const char *type, con
     b.insert(b.end(), val.begin(), val.end());
 }
 
+float half_to_float(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1Fu, man = h & 0x3FFu, x;
+    if (exp == 0) {
+        if (man == 0) x = sign;
+        else {                                   // subnormal: normalise
+            int e = -1;
+            do { man <<= 1; e++; } while (!(man & 0x400u));
+            x = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3FFu) << 13);
+        }
+    } else if (exp == 31) x = sign | 0x7F800000u | (man << 13);
+    else x = sign | ((exp + 112u) << 23) | (man << 13);
+    float f;
+    std::memcpy(&f, &x, 4);
+    return f;
+}
+
+// OpenEXR ZIP block coding: bytes split into even/odd halves, delta-predicted, deflated; stored raw if that is not
+// smaller (OpenEXR file layout document, "ZIP_COMPRESSION"; the reference gets it from tinyexr's SaveEXR).
+std::vector<unsigned char> exr_zip_encode(const std::vector<unsigned char> &raw) {
+    const size_t n = raw.size();
+    std::vector<unsigned char> tmp(n);
+    {
+        unsigned char *t1 = tmp.data(), *t2 = tmp.data() + (n + 1) / 2;
+        for (size_t i = 0; i < n; i++) { if (i & 1) *t2++ = raw[i]; else *t1++ = raw[i]; }
+    }
+    {
+        int p = tmp.empty() ? 0 : tmp[0];
+        for (size_t i = 1; i < n; i++) { int d = (int)tmp[i] - p + (128 + 256); p = tmp[i]; tmp[i] = (unsigned char)d; }
+    }
+    uLongf zlen = compressBound((uLong)n);
+    std::vector<unsigned char> z(zlen);
+    if (compress2(z.data(), &zlen, tmp.data(), (uLong)n, Z_DEFAULT_COMPRESSION) != Z_OK) throw std::runtime_error("EXR: deflate failed");
+    if (zlen >= n) return raw;
+    z.resize(zlen);
+    return z;
+}
+void exr_zip_decode(const unsigned char *src, size_t src_len, std::vector<unsigned char> &raw) {
+    const size_t n = raw.size();
+    if (src_len == n) { std::memcpy(raw.data(), src, n); return; }        // stored uncompressed
+    std::vector<unsigned char> tmp(n);
+    uLongf out_len = (uLongf)n;
+    if (uncompress(tmp.data(), &out_len, src, (uLong)src_len) != Z_OK || out_len != n) throw std::runtime_error("EXR: inflate failed");
+    for (size_t i = 1; i < n; i++) tmp[i] = (unsigned char)((int)tmp[i - 1] + (int)tmp[i] - 128);
+    const unsigned char *t1 = tmp.data(), *t2 = tmp.data() + (n + 1) / 2;
+    for (size_t i = 0; i < n; i++) raw[i] = (i & 1) ? *t2++ : *t1++;
+}
+void exr_rle_decode(const unsigned char *src, size_t src_len, std::vector<unsigned char> &raw) {
+    const size_t n = raw.size();
+    if (src_len == n) { std::memcpy(raw.data(), src, n); return; }
+    std::vector<unsigned char> tmp(n);
+    size_t o = 0, i = 0;
+    while (i < src_len) {
+        int c = (signed char)src[i++];
+        if (c < 0) { size_t cnt = (size_t)(-c); if (i + cnt > src_len || o + cnt > n) throw std::runtime_error("EXR: bad RLE"); std::memcpy(&tmp[o], &src[i], cnt); i += cnt; o += cnt; }
+        else { size_t cnt = (size_t)c + 1; if (i >= src_len || o + cnt > n) throw std::runtime_error("EXR: bad RLE"); std::memset(&tmp[o], src[i++], cnt); o += cnt; }
+    }
+    if (o != n) throw std::runtime_error("EXR: bad RLE length");
+    for (size_t k = 1; k < n; k++) tmp[k] = (unsigned char)((int)tmp[k - 1] + (int)tmp[k] - 128);
+    const unsigned char *t1 = tmp.data(), *t2 = tmp.data() + (n + 1) / 2;
+    for (size_t k = 0; k < n; k++) raw[k] = (k & 1) ? *t2++ : *t1++;
+}
+
+// RGB half-float scanline file, channels B, G, R. Like tinyexr's SaveEXR (which the reference calls with fp16 output,
+// src/image.cpp:155-171): no compression when both extents are < 16, otherwise ZIP in 16-scanline blocks.
 void write_exr_half(const std::string &filename, int w, int h, const double *rgb) {
+    const bool zip = !(w < 16 && h < 16);
+    const int lines_per_block = zip ? 16 : 1;
     std::vector<unsigned char> b;
     put32(b, 20000630u);  // magic
     put32(b, 2u);         // version 2, single-part scanline
@@ -63,7 +137,7 @@ void write_exr_half(const std::string &filename, int w, int h, const double *rgb
         v.push_back(0);
         attr(b, "channels", "chlist", v);
     }
-    { std::vector<unsigned char> v{0 /*NO_COMPRESSION*/}; attr(b, "compression", "compression", v); }
+    { std::vector<unsigned char> v{(unsigned char)(zip ? 3 /*ZIP*/ : 0 /*NONE*/)}; attr(b, "compression", "compression", v); }
     { std::vector<unsigned char> v; put32(v, 0); put32(v, 0); put32(v, (uint32_t)(w - 1)); put32(v, (uint32_t)(h - 1));
       attr(b, "dataWindow", "box2i", v); attr(b, "displayWindow", "box2i", v); }
     { std::vector<unsigned char> v{0 /*INCREASING_Y*/}; attr(b, "lineOrder", "lineOrder", v); }
@@ -71,22 +145,118 @@ void write_exr_half(const std::string &filename, int w, int h, const double *rgb
     { std::vector<unsigned char> v; put32(v, 0); put32(v, 0); attr(b, "screenWindowCenter", "v2f", v); }
     { std::vector<unsigned char> v; float one = 1.0f; uint32_t u; std::memcpy(&u, &one, 4); put32(v, u); attr(b, "screenWindowWidth", "float", v); }
     b.push_back(0); // end of header
-    size_t table = b.size();
-    size_t line_bytes = (size_t)w * 3 * 2;
-    size_t first = table + (size_t)h * 8;
-    for (int y = 0; y < h; y++) put64(b, (uint64_t)(first + (size_t)y * (8 + line_bytes)));
-    for (int y = 0; y < h; y++) {
-        put32(b, (uint32_t)y);
-        put32(b, (uint32_t)line_bytes);
-        for (int c : {2, 1, 0}) // B, G, R planes
-            for (int x = 0; x < w; x++) {
-                uint16_t hv = float_to_half((float)rgb[((size_t)y * w + x) * 3 + c]);
-                b.push_back((unsigned char)(hv & 0xFF)); b.push_back((unsigned char)(hv >> 8));
-            }
+    const int nblocks = (h + lines_per_block - 1) / lines_per_block;
+    const size_t table = b.size();
+    b.resize(table + (size_t)nblocks * 8);
+    for (int blk = 0; blk < nblocks; blk++) {
+        const int y0 = blk * lines_per_block, y1 = std::min(h, y0 + lines_per_block);
+        std::vector<unsigned char> raw;
+        raw.reserve((size_t)(y1 - y0) * w * 6);
+        for (int y = y0; y < y1; y++)
+            for (int c : {2, 1, 0}) // B, G, R planes of the scanline
+                for (int x = 0; x < w; x++) {
+                    uint16_t hv = float_to_half((float)rgb[((size_t)y * w + x) * 3 + c]);
+                    raw.push_back((unsigned char)(hv & 0xFF)); raw.push_back((unsigned char)(hv >> 8));
+                }
+        const std::vector<unsigned char> payload = zip ? exr_zip_encode(raw) : raw;
+        const uint64_t off = b.size();
+        for (int i = 0; i < 8; i++) b[table + (size_t)blk * 8 + i] = (unsigned char)(off >> (8 * i));
+        put32(b, (uint32_t)y0);
+        put32(b, (uint32_t)payload.size());
+        b.insert(b.end(), payload.begin(), payload.end());
     }
     std::ofstream ofs(filename, std::ios::binary);
     if (!ofs) throw std::runtime_error("Failure when writing image: " + filename);
     ofs.write((const char *)b.data(), (std::streamsize)b.size());
+}
+
+// Scanline OpenEXR reader: single part, compression NONE / RLE / ZIPS / ZIP, HALF / FLOAT / UINT channels.
+// Returns what tinyexr's LoadEXR hands the reference (src/image.cpp:56-72,109-127): the R, G, B channels as fp32
+// (a single-channel file is replicated to all three).
+void read_exr_rgb(const std::string &filename, int *width, int *height, std::vector<float> *rgb) {
+    std::ifstream ifs(filename, std::ios::binary);
+    if (!ifs) throw std::runtime_error("Failure when loading image: " + filename);
+    std::vector<unsigned char> f((std::istreambuf_iterator<char>(ifs)), std::istreambuf_iterator<char>());
+    size_t pos = 0;
+    auto need = [&](size_t n) { if (pos + n > f.size()) throw std::runtime_error("Failure when loading image: truncated " + filename); };
+    auto rd32 = [&]() { need(4); uint32_t v = f[pos] | (f[pos + 1] << 8) | (f[pos + 2] << 16) | ((uint32_t)f[pos + 3] << 24); pos += 4; return v; };
+    auto rdstr = [&]() { std::string s; for (;;) { need(1); char c = (char)f[pos++]; if (!c) break; s.push_back(c); } return s; };
+    if (rd32() != 20000630u) throw std::runtime_error("Failure when loading image: not an OpenEXR file: " + filename);
+    uint32_t version = rd32();
+    if (version & 0x1E00u) throw std::runtime_error("Unsupported image format: tiled / deep / multi-part OpenEXR: " + filename);
+    struct Chan { std::string name; int type; };
+    std::vector<Chan> chans;
+    int compression = -1, x0 = 0, y0 = 0, x1 = -1, y1 = -1, line_order = 0;
+    for (;;) {
+        std::string name = rdstr();
+        if (name.empty()) break;
+        std::string type = rdstr();
+        uint32_t n = rd32();
+        need(n);
+        const size_t vpos = pos;
+        if (name == "channels") {
+            size_t p = vpos;
+            while (p < vpos + n && f[p]) {
+                Chan c;
+                while (f[p]) c.name.push_back((char)f[p++]);
+                p++;
+                c.type = (int)(f[p] | (f[p + 1] << 8));
+                p += 4 + 4;                               // pixel type, pLinear + reserved
+                uint32_t xs = f[p] | (f[p + 1] << 8), ys = f[p + 4] | (f[p + 5] << 8);
+                p += 8;
+                if (xs != 1 || ys != 1) throw std::runtime_error("Unsupported image format: subsampled OpenEXR channel: " + filename);
+                chans.push_back(c);
+            }
+        } else if (name == "compression") compression = f[vpos];
+        else if (name == "dataWindow") { pos = vpos; x0 = (int)rd32(); y0 = (int)rd32(); x1 = (int)rd32(); y1 = (int)rd32(); }
+        else if (name == "lineOrder") line_order = f[vpos];
+        pos = vpos + n;
+    }
+    (void)line_order;   // blocks carry their own y coordinate
+    const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+    if (w <= 0 || h <= 0 || chans.empty()) throw std::runtime_error("Failure when loading image: bad OpenEXR header: " + filename);
+    int lines_per_block;
+    if (compression == 0 || compression == 1 || compression == 2) lines_per_block = 1;
+    else if (compression == 3) lines_per_block = 16;
+    else throw std::runtime_error("Unsupported image format: OpenEXR compression " + std::to_string(compression) + " (NONE, RLE, ZIPS, ZIP are read): " + filename);
+    size_t bytes_per_px = 0;
+    for (auto &c : chans) bytes_per_px += (c.type == 1) ? 2 : 4;
+    int ir = -1, ig = -1, ib = -1;
+    for (size_t i = 0; i < chans.size(); i++) { if (chans[i].name == "R") ir = (int)i; if (chans[i].name == "G") ig = (int)i; if (chans[i].name == "B") ib = (int)i; }
+    if (chans.size() == 1) ir = ig = ib = 0;
+    if (ir < 0 || ig < 0 || ib < 0) throw std::runtime_error("Failure when loading image: OpenEXR without R, G, B channels: " + filename);
+    const int nblocks = (h + lines_per_block - 1) / lines_per_block;
+    need((size_t)nblocks * 8);
+    std::vector<uint64_t> offs((size_t)nblocks);
+    for (int i = 0; i < nblocks; i++) { uint64_t v = 0; for (int k = 0; k < 8; k++) v |= (uint64_t)f[pos + k] << (8 * k); pos += 8; offs[(size_t)i] = v; }
+    rgb->assign((size_t)w * h * 3, 0.f);
+    for (int blk = 0; blk < nblocks; blk++) {
+        pos = (size_t)offs[(size_t)blk];
+        int by = (int)rd32() - y0;
+        uint32_t len = rd32();
+        need(len);
+        if (by < 0 || by >= h) throw std::runtime_error("Failure when loading image: bad OpenEXR block: " + filename);
+        const int lines = std::min(lines_per_block, h - by);
+        std::vector<unsigned char> raw((size_t)lines * w * bytes_per_px);
+        if (compression == 0) { if (len != raw.size()) throw std::runtime_error("Failure when loading image: bad OpenEXR block size: " + filename); std::memcpy(raw.data(), &f[pos], len); }
+        else if (compression == 1) exr_rle_decode(&f[pos], len, raw);
+        else exr_zip_decode(&f[pos], len, raw);
+        size_t p = 0;
+        for (int ly = 0; ly < lines; ly++)
+            for (size_t c = 0; c < chans.size(); c++) {
+                for (int x = 0; x < w; x++) {
+                    float v;
+                    if (chans[c].type == 1) { v = half_to_float((uint16_t)(raw[p] | (raw[p + 1] << 8))); p += 2; }
+                    else if (chans[c].type == 2) { std::memcpy(&v, &raw[p], 4); p += 4; }
+                    else { uint32_t u; std::memcpy(&u, &raw[p], 4); v = (float)u; p += 4; }
+                    float *px = &(*rgb)[((size_t)(by + ly) * w + x) * 3];
+                    if ((int)c == ir) px[0] = v;
+                    if ((int)c == ig) px[1] = v;
+                    if ((int)c == ib) px[2] = v;
+                }
+            }
+    }
+    *width = w; *height = h;
 }
 
 } // namespace
@@ -130,6 +300,40 @@ void load_texture_file(const std::string &path, int channels, int *width, int *h
         texels->resize(n);
         for (size_t i = 0; i < n; i++) (*texels)[i] = (rgb[3 * i] + rgb[3 * i + 1] + rgb[3 * i + 2]) / 3;
         return;
+    }
+    {
+        std::string low = path;
+        for (auto &ch : low) ch = (char)std::tolower((unsigned char)ch);
+        if (ends_with(low, ".exr")) {
+            // imread3: (R, G, B); imread1: (R + G + B) / 3 evaluated in fp32 like the reference (src/image.cpp:63-65)
+            std::vector<float> rgb;
+            read_exr_rgb(path, width, height, &rgb);
+            const size_t n = (size_t)*width * *height;
+            texels->resize(n * channels);
+            for (size_t i = 0; i < n; i++) {
+                if (channels == 3) for (int c = 0; c < 3; c++) (*texels)[3 * i + c] = (double)rgb[3 * i + c];
+                else (*texels)[i] = (double)((rgb[3 * i] + rgb[3 * i + 1] + rgb[3 * i + 2]) / 3);
+            }
+            return;
+        }
+        if (ends_with(low, ".jpg") || ends_with(low, ".jpeg")) {
+            // decoded natively; 8-bit -> linear exactly as stbi_loadf widens it: (float)(pow(v / 255.0f, 2.2f) * 1.0f),
+            // the float overload of pow as image.cpp (C++) resolves it (src/3rdparty/stb_image.h:1849)
+            std::ifstream jf(path, std::ios::binary);
+            if (!jf) throw std::runtime_error("Failure when loading image: " + path);
+            std::vector<unsigned char> bytes((std::istreambuf_iterator<char>(jf)), std::istreambuf_iterator<char>());
+            std::vector<uint8_t> px;
+            try {
+                decode_jpeg(bytes.data(), bytes.size(), channels, width, height, &px);
+            } catch (const std::exception &e) {
+                throw std::runtime_error("Failure when loading image: " + path + " (" + e.what() + ")");
+            }
+            float lut[256];
+            for (int v = 0; v < 256; v++) lut[v] = (float)(std::pow(v / 255.0f, 2.2f) * 1.0f);
+            texels->resize(px.size());
+            for (size_t i = 0; i < px.size(); i++) (*texels)[i] = (double)lut[px[i]];
+            return;
+        }
     }
     std::string raw = path + ".gdtex";
     std::ifstream ifs(raw, std::ios::binary);

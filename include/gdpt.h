@@ -224,6 +224,13 @@ int gdpt_gradient_path_render(GdptScene *scene, const GdptRenderParams *params, 
 /* By suffix: ".pfm" (fp32, header "PF\nW H\n-1\n", rows as stored) or ".exr" (fp16 RGB scanline). */
 int gdpt_imwrite(const char *filename, int width, int height, const double *rgb);
 
+/* ---- input images (host only) ----
+ * imread1 / imread3 of the reference (src/image.cpp:26-133) for channels = 1 / 3: fp64 texels, row-major, top row
+ * first. ".jpg"/".jpeg": own baseline decoder returning stb_image's samples, widened like stbi_loadf; ".pfm"; other
+ * suffixes through a pre-decoded "<file>.gdtex" companion. Free with gdpt_image_free. */
+int gdpt_imread(const char *filename, int channels, int *width, int *height, double **texels);
+void gdpt_image_free(double *texels);
+
 /* ---- diagnostics (host only, no GPU) ----
  * Builds the acceleration structure that gdpt_scene_upload would build over `n` primitive boxes (bounds6 = n x
  * {min xyz, max xyz}, fp32) — the replacement for the reference's Embree commit, src/scene.cpp:20-31 — and verifies it:

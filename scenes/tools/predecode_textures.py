@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Pre-decodes the bitmap textures a scene XML references into `<file>.gdtex` companions, so the hot path needs
-no image codec (the reference decodes through stb_image at load time, src/image.cpp:84-108).
+"""Pre-decodes bitmap textures a scene XML references into `<file>.gdtex` companions, for formats the library does
+not decode itself (PNG, TGA, BMP, progressive JPEG ...; baseline JPEG, PFM and scanline EXR are read natively — the
+reference decodes everything through stb_image / tinyexr at load time, src/image.cpp:26-133).
 
 Format GDTEX2: b"GDTEX2\\n", int32 width, height, channels(=3), uint32 zlen, zlib(uint8 RGB texels, row-major).
 The loader widens 8-bit texels exactly as stbi_loadf does: (float)pow(v/255.0f, 2.2f) (src/3rdparty/stb_image.h:1849).
@@ -25,7 +26,7 @@ def main(xml_path):
     for rel in files:
         src = os.path.join(base, rel)
         if rel.lower().endswith((".pfm", ".exr")):
-            print("skip (not an 8-bit codec):", rel)
+            print("skip (read natively):", rel)
             continue
         img = np.asarray(Image.open(src).convert("RGB"), dtype=np.uint8)
         h, w, _ = img.shape

@@ -136,3 +136,24 @@ def test_cli_drop_in(G, scene_tmp, tmp_path):
     bad.write_text('<scene version="0.5.0"><integrator type="bogus"/></scene>')
     r = subprocess.run([exe, str(bad)], capture_output=True, text=True)
     assert r.returncode != 0 and "Unsupported integrator" in r.stderr
+
+
+@pytest.mark.gpu
+def test_pipeline_output_agrees_with_the_reference_own_render(G):
+    """End-to-end anchor on a file the reference itself produced: gdpt_renders/tmp_gdpt_0.04.exr (cbox_gdpt, alpha 0.04,
+    512x512, fp16 ZIP EXR written by lajolla; its spp is unknown). tests/golden/ref_images.json holds the per-channel
+    means and the 16x16 grid of 32x32-pixel block means of that file (read by the reference's own LoadEXR).
+    A Monte-Carlo render cannot match per pixel, so the statistics are compared: channel means within 1.5 %, block means
+    within 6 % relative L2 (measured: 0.1-0.3 % and 3.7 % at 64 spp)."""
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_images.json")))["reference_renders"]["gdpt_renders/tmp_gdpt_0.04.exr"]
+    sc = G.Scene(G.parse_scene(os.path.join(ROOT, "scenes", "cbox", "cbox_gdpt.xml")))
+    out = sc.gradient_path_render(64, G.RNG_SAMPLE, alpha=0.04)
+    h, w, _ = out.shape
+    assert (w, h) == (gold["width"], gold["height"])
+    ratio = out.mean(axis=(0, 1)) / np.array(gold["mean"])
+    assert np.all(np.abs(ratio - 1) < 0.015), ratio
+    bs = 32
+    thumb = out.reshape(h // bs, bs, w // bs, bs, 3).mean(axis=(1, 3))
+    ref = np.array(gold["block_mean_32"])
+    assert np.linalg.norm(thumb - ref) / np.linalg.norm(ref) < 0.06

@@ -122,7 +122,7 @@ def test_disney_lobes_gradpath(G, O, scene_tmp, scene):
 
 def test_sponza_textures_sphere_light_big_bvh(G, O, scene_tmp):
     """BASELINE config 4 geometry: 66 445 triangles in 37 meshes with vertex normals + 1 sphere light, 10 image
-    textures (mip levels at the primary vertex), BVH walked from HBM. Textures are the pre-decoded .gdtex companions."""
+    textures (mip levels at the primary vertex), BVH walked from HBM. Textures are decoded from the scene's JPEGs by the build's own decoder."""
     xml = scene_variant(scene_tmp, "sponza/sponza.xml", width=96, height=72)
     sd = G.parse_scene(xml)
     sc = G.Scene(sd)

@@ -20,35 +20,121 @@ def test_pfm_layout(G, tmp_path):
     assert np.array_equal(data, img.astype(np.float32))          # top row first, as stored
 
 
-def test_exr_half_scanline(G, tmp_path):
+def half_like_tinyexr(a):
+    """fp32 -> fp16 as the reference's writer rounds (tinyexr float_to_half_full, src/3rdparty/tinyexr.h:889-924): the
+    first dropped bit decides, ties go away from zero; float subnormals flush to zero."""
+    x = np.asarray(a, dtype=np.float32).view(np.uint32).astype(np.int64)
+    sign = (x >> 16) & 0x8000
+    e = (x >> 23) & 0xFF
+    m = x & 0x7FFFFF
+    ne = e - 127 + 15
+    h = np.zeros_like(x)
+    normal = (e > 0) & (e < 255) & (ne > 0) & (ne < 31)
+    h = np.where(normal, (ne.clip(0, 31) << 10) | (m >> 13), h)
+    h = np.where(normal & ((m & 0x1000) != 0), h + 1, h)
+    sub = (e > 0) & (e < 255) & (ne <= 0) & (14 - ne <= 24)
+    sh = (14 - ne).clip(1, 62)
+    mant = m | 0x800000
+    h = np.where(sub, (mant >> sh) + ((mant >> (sh - 1)) & 1), h)
+    h = np.where((e > 0) & (e < 255) & (ne >= 31), 0x7C00, h)
+    h = np.where(e == 255, 0x7C00 | np.where(m != 0, 0x200, 0), h)
+    return (sign | h).astype(np.uint16).view(np.float16)
+
+
+def test_exr_write_read_round_trip(G, tmp_path):
+    """ZIP-compressed half scanline file (what tinyexr's SaveEXR writes for images >= 16 pixels in an extent,
+    src/image.cpp:155-171) read back by the build's own reader; rounding as the reference's writer does it."""
     img = ramp() * 3.0 - 0.5
     img[0, 0] = [65504.0, 1e-8, -2.0]
+    img[0, 1] = [3.1259765625, -3.1259765625, 70000.0]      # exact ties (go away from zero) and overflow to inf
+    img[0, 2] = [6.1e-5, 5.96e-8, 2.98e-8]                   # half subnormals
     p = tmp_path / "o.exr"
     G.imwrite(str(p), img)
     raw = p.read_bytes()
     assert struct.unpack("<I", raw[:4])[0] == 20000630 and raw[4] == 2
-    assert b"channels\x00chlist\x00" in raw and b"compression\x00compression\x00" in raw
-    # parse: header ends with a lone NUL after the last attribute; then the offset table and the scanlines
-    pos = 8
-    while raw[pos] != 0:
-        pos = raw.index(b"\x00", pos) + 1          # name
-        pos = raw.index(b"\x00", pos) + 1          # type
-        size = struct.unpack("<i", raw[pos:pos + 4])[0]
-        pos += 4 + size
-    pos += 1
-    w, h = 32, 24
-    offsets = struct.unpack("<%dQ" % h, raw[pos:pos + 8 * h])
-    got = np.empty((h, w, 3), dtype=np.float16)
-    for y in range(h):
-        o = offsets[y]
-        yy, nbytes = struct.unpack("<ii", raw[o:o + 8])
-        assert yy == y and nbytes == w * 3 * 2
-        line = np.frombuffer(raw[o + 8:o + 8 + nbytes], dtype="<f2").reshape(3, w)     # B, G, R planes
-        got[y, :, 2], got[y, :, 1], got[y, :, 0] = line[0], line[1], line[2]
-    want = img.astype(np.float32).astype(np.float16)     # round-to-nearest-even, like numpy
-    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
-    # fp16 storage keeps the reference test's 1e-2 tolerance
-    assert np.max(np.abs(got[1:].astype(np.float64) - img[1:])) < 1e-2
+    assert b"compression\x00compression\x00\x01\x00\x00\x00\x03" in raw              # ZIP
+    got = G.imread(str(p), 3)
+    want = half_like_tinyexr(img.astype(np.float32)).astype(np.float64)
+    assert np.array_equal(got, want)
+    assert got[0, 1, 0] == 3.126953125 and got[0, 1, 1] == -3.126953125 and np.isinf(got[0, 1, 2])
+    assert np.max(np.abs(got[1:] - img[1:])) < 1e-2          # the reference test's tolerance (src/tests/image.cpp)
+    g1 = G.imread(str(p), 1)[..., 0]                          # imread1: (R+G+B)/3 in fp32 (src/image.cpp:63-65)
+    w32 = want.astype(np.float32)
+    assert np.array_equal(g1[1:], ((w32[1:, :, 0] + w32[1:, :, 1] + w32[1:, :, 2]) / np.float32(3)).astype(np.float64))
+
+
+def test_exr_small_images_are_uncompressed(G, tmp_path):
+    img = ramp(8, 5)
+    p = tmp_path / "s.exr"
+    G.imwrite(str(p), img)
+    raw = p.read_bytes()
+    assert b"compression\x00compression\x00\x01\x00\x00\x00\x00" in raw              # NONE below 16x16
+    assert np.array_equal(G.imread(str(p), 3), half_like_tinyexr(img.astype(np.float32)).astype(np.float64))
+
+
+def _golden():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_images.json")))
+
+
+def _test_picture(w, h):
+    x = np.arange(w, dtype=np.float64)[None, :]
+    y = np.arange(h, dtype=np.float64)[:, None]
+    u, v = (x + 0.5) / w, (y + 0.5) / h
+    img = np.zeros((h, w, 3))
+    img[..., 0] = u * u * 3.0 - 0.25
+    img[..., 1] = (v - 0.5) * 1e-5 + 0 * u
+    img[..., 2] = 100.0 * u * v + 1.0 / 1024.0
+    img[1, 1, 2] += 70000.0
+    return img
+
+
+def test_exr_against_reference_written_files(G, tmp_path):
+    """tests/golden/ref_images.json holds EXR files written by the reference's own imwrite (tinyexr) and the pixel
+    checksum the reference's reader computes from them and from THIS build's files of the same picture."""
+    import base64
+    import zlib
+    for key, rec in _golden()["exr"].items():
+        w, h = rec["width"], rec["height"]
+        ref_file = tmp_path / f"ref_{key}.exr"
+        ref_file.write_bytes(base64.b64decode(rec["reference_file_b64"]))
+        seen = G.imread(str(ref_file), 3)                    # own reader on the reference's file
+        assert seen.shape == (h, w, 3)
+        assert zlib.crc32(seen.astype(np.float32).tobytes()) == rec["pixels_crc32_as_read_by_reference"]
+        own = tmp_path / f"own_{key}.exr"
+        G.imwrite(str(own), _test_picture(w, h))            # own writer: the bytes the reference reader validated
+        assert zlib.crc32(own.read_bytes()) == rec["own_file_crc32"]
+        assert np.array_equal(G.imread(str(own), 3), seen)
+
+
+def test_jpeg_decoder_matches_the_reference_decoder(G):
+    """Every sponza texture through the build's baseline JPEG decoder == what the reference's imread3 / imread1
+    (stb_image v2.27 as vendored there) return: CRC-32 of the fp32 texels, generated by oracle/ref_img.cpp."""
+    import os
+    import zlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = _golden()
+    assert len(gold["imread3"]) >= 11
+    for name, rec in gold["imread3"].items():
+        path = os.path.join(root, "scenes", "sponza", "textures", name)
+        a = G.imread(path, 3)
+        assert a.shape == (rec["height"], rec["width"], 3)
+        assert zlib.crc32(a.astype(np.float32).tobytes()) == rec["crc32"], name
+        assert np.allclose(a[0, :2].reshape(-1), rec["first"], rtol=1e-7)
+        a1 = G.imread(path, 1)
+        assert zlib.crc32(a1.astype(np.float32).tobytes()) == gold["imread1"][name]["crc32"], name
+
+
+def test_jpeg_decoder_rejects_what_it_does_not_decode(G, tmp_path):
+    import pytest
+    p = tmp_path / "bad.jpg"
+    p.write_bytes(b"\xff\xd8\xff\xc2\x00\x0b\x08\x00\x10\x00\x10\x01\x01\x11\x00")     # SOF2: progressive
+    with pytest.raises(G.GdptError, match="progressive"):
+        G.imread(str(p), 3)
+    p.write_bytes(b"not a jpeg")
+    with pytest.raises(G.GdptError):
+        G.imread(str(p), 3)
 
 
 def test_unknown_suffix_writes_nothing(G, tmp_path):
