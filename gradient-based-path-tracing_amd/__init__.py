@@ -53,6 +53,8 @@ def lib():
         L.gdpt_scene_info.argtypes = [vp] + [C.POINTER(C.c_int32)] * 4
         L.gdpt_render.argtypes = [vp, C.POINTER(defs.GdptRenderParams), dp, dp, dp, dp, dp, C.POINTER(defs.GdptRenderStats)]
         L.gdpt_render_device.argtypes = [vp, C.POINTER(defs.GdptRenderParams), vp, vp, vp, vp, vp, vp, C.POINTER(defs.GdptRenderStats)]
+        L.gdpt_path_render.argtypes = [vp, C.POINTER(defs.GdptRenderParams), dp, C.POINTER(defs.GdptRenderStats)]
+        L.gdpt_path_render_device.argtypes = [vp, C.POINTER(defs.GdptRenderParams), vp, vp, C.POINTER(defs.GdptRenderStats)]
         L.gdpt_assemble_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.gdpt_poisson_solve.argtypes = [C.c_int, C.c_int, dp, dp, dp, C.c_double, dp]
         L.gdpt_poisson_solve_ex.argtypes = [C.c_int, C.c_int, dp, dp, dp, C.c_double, dp, C.c_int, C.c_double, C.c_int,
@@ -156,6 +158,20 @@ class Scene:
         _check(lib().gdpt_render_device(self.handle, C.byref(p), *[C.c_void_p(int(x)) for x in ptrs],
                                         C.c_void_p(int(stream) if stream else 0), C.byref(st) if st is not None else None))
         return st
+
+    def path_render(self, spp=0, rng_scheme=defs.RNG_SAMPLE, rows=(0, 0), want_counts=False):
+        """Integrator::Path (path_render, src/render.cpp:74-117): HxWx3 float64 image + GdptRenderStats."""
+        img = np.zeros((self.height, self.width, 3), dtype=np.float64)
+        st = defs.GdptRenderStats()
+        if want_counts:
+            st.nodes_visited = 2 ** 64 - 1
+        p = _params(spp, rng_scheme, rows)
+        _check(lib().gdpt_path_render(self.handle, C.byref(p), _dp(img), C.byref(st)))
+        return img, st
+
+    def path_render_device(self, ptr, spp=0, rng_scheme=defs.RNG_SAMPLE, rows=(0, 0), stream=None):
+        p = _params(spp, rng_scheme, rows)
+        _check(lib().gdpt_path_render_device(self.handle, C.byref(p), C.c_void_p(int(ptr)), C.c_void_p(int(stream) if stream else 0), None))
 
     def gradient_path_render(self, spp=0, rng_scheme=defs.RNG_SAMPLE, alpha=0.04, return_buffers=False):
         """Whole Integrator::GradPath: render + assembly + screened-Poisson solve (src/render.cpp:257-370)."""

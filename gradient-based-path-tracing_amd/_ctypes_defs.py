@@ -55,7 +55,7 @@ class GdptSceneDesc(C.Structure):
                 ("num_lights", C.c_int32), ("num_images", C.c_int32),
                 ("materials", C.POINTER(GdptMaterial)), ("shapes", C.POINTER(GdptShape)),
                 ("lights", C.POINTER(GdptLight)), ("images", C.POINTER(GdptImage)),
-                ("output_filename", C.c_char * 256)]
+                ("output_filename", C.c_char * 256), ("has_envmap", C.c_int32), ("_pad", C.c_int32)]
 
 
 class GdptRenderParams(C.Structure):

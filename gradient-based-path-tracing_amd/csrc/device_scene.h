@@ -63,6 +63,19 @@ struct DevSphere {
     int32_t shape_id, material_id, light_id, pad;
 };
 
+// One emitter of Integrator::Path (DiffuseAreaLight, src/lights/diffuse_area_light.inl). Mesh emitters carry their
+// triangle sampling table (init_sampling_dist, src/shapes/triangle_mesh.inl:60-75) in DevSceneView::light_tri_*.
+struct DevLight {
+    double intensity[3];
+    double area;             // surface_area of the shape
+    int32_t is_sphere;       // 0: triangle mesh, 1: sphere (index into DevSceneView::spheres)
+    int32_t sphere_index;
+    int32_t tri_first;       // first triangle of this emitter in light_tri_pos / light_tri_nrm
+    int32_t tri_count;
+    int32_t cdf_first;       // first entry of this emitter's cdf (tri_count + 1 entries) in light_tri_cdf
+    int32_t has_normals;
+};
+
 struct DevImage {        // mip chain of one Mipmap1/Mipmap3 (src/mipmap.h:27-48), texels fp64 in one pool
     int32_t channels, num_levels;
     int32_t width[8], height[8];
@@ -90,6 +103,13 @@ struct DevSceneView {
     const double *light_intensity;          // 3 per area light
     const DevImage *images;
     const double *texels;
+    // Integrator::Path: emitter selection table (src/scene.cpp:44-53; cdf has num_lights + 1 entries, the last one keeps
+    // the total like make_table_dist_1d leaves it) and the emitters' own tables / fp64 triangles
+    const DevLight *lights;
+    const double *light_pmf, *light_cdf;
+    const double *light_tri_cdf;
+    const double *light_tri_pos;            // 9 doubles per emitter triangle: v0, v1, v2
+    const double *light_tri_nrm;            // 9 doubles per emitter triangle: n0, n1, n2 (zeros when the mesh has none)
     int32_t num_nodes, num_nodes4, num_prims, num_tris, num_spheres;
     int32_t num_materials, num_lights, num_images;
     int32_t max_depth, rr_depth;

@@ -41,6 +41,7 @@ struct GdptScene {
     DevSceneView view{};
     int bvh_depth = 0;
     int wide_stack_need = 0;
+    bool has_envmap = false;
     int scene_spp = 0;             // <sampler sampleCount> of the description (default spp)
     bool one_sided = true, lambert_only = true;
     std::vector<void *> allocations;
@@ -225,6 +226,59 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     std::vector<double> light_intensity;
     for (int l = 0; l < desc->num_lights; l++) for (int k = 0; k < 3; k++) light_intensity.push_back(desc->lights[l].intensity[k]);
 
+    // ---- Integrator::Path emitter tables (same formulas and operation order as the reference) ----
+    std::vector<DevLight> dlights;
+    std::vector<double> light_pmf, light_cdf, light_tri_cdf, light_tri_pos, light_tri_nrm;
+    auto table_1d = [](const std::vector<double> &f, std::vector<double> &pmf, std::vector<double> &cdf) {   // src/table_dist.cpp:3-25
+        pmf = f;
+        cdf.assign(f.size() + 1, 0.0);
+        for (size_t i = 0; i < f.size(); i++) cdf[i + 1] = cdf[i] + pmf[i];
+        const double total = cdf.back();
+        if (total > 0) { for (size_t i = 0; i < pmf.size(); i++) { pmf[i] /= total; cdf[i] /= total; } }
+        else {
+            for (size_t i = 0; i < pmf.size(); i++) { pmf[i] = 1.0 / (double)pmf.size(); cdf[i] = (double)i / (double)pmf.size(); }
+            cdf.back() = 1;
+        }
+    };
+    {
+        std::vector<int> sphere_index_of_shape((size_t)desc->num_shapes, -1);
+        { int k = 0; for (int s = 0; s < desc->num_shapes; s++) if (desc->shapes[s].type == GDPT_SHAPE_SPHERE) sphere_index_of_shape[(size_t)s] = k++; }
+        std::vector<double> power;
+        for (int l = 0; l < desc->num_lights; l++) {
+            const GdptLight &lt = desc->lights[l];
+            if (lt.shape_id < 0 || lt.shape_id >= desc->num_shapes) throw std::runtime_error("gdpt_scene_upload: light without a shape");
+            const GdptShape &sh = desc->shapes[lt.shape_id];
+            DevLight dl{};
+            for (int k = 0; k < 3; k++) dl.intensity[k] = lt.intensity[k];
+            if (sh.type == GDPT_SHAPE_SPHERE) {
+                dl.is_sphere = 1; dl.sphere_index = sphere_index_of_shape[(size_t)lt.shape_id];
+                dl.area = 4 * 3.14159265358979323846 * sh.radius * sh.radius;                 // sphere.inl:207-209
+            } else {
+                dl.tri_first = (int)(light_tri_pos.size() / 9); dl.tri_count = sh.num_triangles;
+                dl.cdf_first = (int)light_tri_cdf.size(); dl.has_normals = sh.normals ? 1 : 0;
+                std::vector<double> areas((size_t)sh.num_triangles), pmf, cdf;
+                double total = 0;
+                for (int t = 0; t < sh.num_triangles; t++) {
+                    const int *ix = sh.indices + 3 * t;
+                    double p[3][3];
+                    for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { p[i][k] = sh.positions[3 * ix[i] + k]; light_tri_pos.push_back(p[i][k]); }
+                    for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) light_tri_nrm.push_back(sh.normals ? sh.normals[3 * ix[i] + k] : 0.0);
+                    const double e1[3] = {p[1][0] - p[0][0], p[1][1] - p[0][1], p[1][2] - p[0][2]}, e2[3] = {p[2][0] - p[0][0], p[2][1] - p[0][1], p[2][2] - p[0][2]};
+                    const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+                    areas[(size_t)t] = std::sqrt(cx * cx + cy * cy + cz * cz) / 2;               // triangle_mesh.inl:70
+                    total += areas[(size_t)t];
+                }
+                table_1d(areas, pmf, cdf);
+                light_tri_cdf.insert(light_tri_cdf.end(), cdf.begin(), cdf.end());
+                dl.area = total;
+            }
+            const double lum = lt.intensity[0] * 0.212671 + lt.intensity[1] * 0.715160 + lt.intensity[2] * 0.072169;   // src/spectrum.h:33-35
+            power.push_back(lum * dl.area * 3.14159265358979323846);                              // diffuse_area_light.inl:1-3
+            dlights.push_back(dl);
+        }
+        if (!power.empty()) table_1d(power, light_pmf, light_cdf);
+    }
+
     DevSceneView &v = sc->view;
     std::memcpy(v.cam.sample_to_cam, cam.sample_to_cam, sizeof(v.cam.sample_to_cam));
     std::memcpy(v.cam.cam_to_world, cam.cam_to_world, sizeof(v.cam.cam_to_world));
@@ -243,6 +297,11 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     v.light_intensity = sc->keep(upload(light_intensity));
     v.images = sc->keep(upload(images));
     v.texels = sc->keep(upload(texels));
+    v.lights = sc->keep(upload(dlights));
+    v.light_pmf = sc->keep(upload(light_pmf)); v.light_cdf = sc->keep(upload(light_cdf));
+    v.light_tri_cdf = sc->keep(upload(light_tri_cdf));
+    v.light_tri_pos = sc->keep(upload(light_tri_pos)); v.light_tri_nrm = sc->keep(upload(light_tri_nrm));
+    sc->has_envmap = desc->has_envmap != 0;
     v.num_nodes = (int)bvh.nodes.size(); v.num_nodes4 = (int)nodes4.size(); v.num_prims = (int)prims.size();
     v.num_tris = (int)tris.size(); v.num_spheres = (int)spheres.size();
     v.num_materials = desc->num_materials; v.num_lights = desc->num_lights; v.num_images = desc->num_images;
@@ -340,6 +399,41 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     }
 }
 
+// Integrator::Path: enqueues one render of `img`; returns after enqueue unless stats are requested.
+void path_render_device_impl(GdptScene *sc, const GdptRenderParams *params, double *img, hipStream_t stream, GdptRenderStats *stats) {
+    ck(hipSetDevice(sc->device), "hipSetDevice");
+    if (sc->has_envmap) throw std::runtime_error("gdpt_path_render: environment-map emitters are not supported by the Path entry points");
+    if (sc->view.num_lights <= 0) throw std::runtime_error("gdpt_path_render: the scene has no emitter to sample");
+    Band b = resolve(sc, params);
+    if (b.spp <= 0) b.spp = sc->scene_spp;
+    if (b.spp <= 0) throw std::runtime_error("gdpt_path_render: samples per pixel must be > 0");
+    if (!img) throw std::runtime_error("gdpt_path_render: null output buffer");
+    gdpt::RenderLaunch rl{};
+    rl.spp = b.spp; rl.rng_scheme = b.rng; rl.row_begin = b.row_begin; rl.row_end = b.row_end; rl.max_depth = b.max_depth;
+    rl.img = img;
+    rl.counters = sc->d_counters;
+    rl.count_traversal = stats && stats->nodes_visited == ~0ull;
+    const char *k = std::getenv("GDPT_LOG2K");
+    rl.force_log2k = k ? std::atoi(k) : -1;
+    ck(hipMemsetAsync(sc->d_counters, 0, sizeof(gdpt::RenderCounters), stream), "hipMemsetAsync(counters)");
+    if (stats) ck(hipEventRecord(sc->ev0, stream), "hipEventRecord");
+    gdpt::launch_path_render(sc->view, rl, stream);
+    if (stats) {
+        ck(hipEventRecord(sc->ev1, stream), "hipEventRecord");
+        ck(hipMemcpyAsync(sc->h_counters, sc->d_counters, sizeof(gdpt::RenderCounters), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(counters)");
+        ck(hipStreamSynchronize(stream), "hipStreamSynchronize(path render)");
+        float ms = 0;
+        ck(hipEventElapsedTime(&ms, sc->ev0, sc->ev1), "hipEventElapsedTime");
+        std::memset(stats, 0, sizeof(*stats));
+        stats->samples = (uint64_t)sc->view.cam.width * (uint64_t)(b.row_end - b.row_begin) * (uint64_t)b.spp;
+        stats->rays = sc->h_counters->rays; stats->bounces = sc->h_counters->bounces;
+        stats->nonfinite_samples = sc->h_counters->nonfinite;
+        stats->nodes_visited = sc->h_counters->nodes; stats->tris_tested = sc->h_counters->prims;
+        stats->render_ms = ms;
+        stats->node_bytes = sizeof(DevBvh4Node);
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -397,6 +491,29 @@ int gdpt_render(GdptScene *scene, const GdptRenderParams *params,
         render_device_impl(scene, params, scene->scene_spp, scene->d_buf[0], scene->d_buf[1], scene->d_buf[2], scene->d_buf[3], scene->d_buf[4],
                            nullptr, stats ? stats : &local);
         for (int k = 0; k < 5; k++) ck(hipMemcpy(host[k], scene->d_buf[k], elems * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
+    });
+}
+
+int gdpt_path_render_device(GdptScene *scene, const GdptRenderParams *params, double *d_img, void *stream, GdptRenderStats *stats) {
+    return gdpt::guarded([&]() {
+        if (!scene) throw std::runtime_error("null scene handle");
+        path_render_device_impl(scene, params, d_img, (hipStream_t)stream, stats);
+    });
+}
+
+int gdpt_path_render(GdptScene *scene, const GdptRenderParams *params, double *img, GdptRenderStats *stats) {
+    return gdpt::guarded([&]() {
+        if (!scene) throw std::runtime_error("null scene handle");
+        if (!img) throw std::runtime_error("gdpt_path_render: null output buffer");
+        ck(hipSetDevice(scene->device), "hipSetDevice");
+        size_t elems = (size_t)scene->view.cam.width * scene->view.cam.height * 3;
+        scene->ensure_buffers(elems);
+        Band b = resolve(scene, params);
+        const bool partial = (b.row_begin != 0 || b.row_end != scene->view.cam.height);
+        if (partial) ck(hipMemcpy(scene->d_buf[0], img, elems * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(H2D)");
+        GdptRenderStats local{};
+        path_render_device_impl(scene, params, scene->d_buf[0], nullptr, stats ? stats : &local);
+        ck(hipMemcpy(img, scene->d_buf[0], elems * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
     });
 }
 

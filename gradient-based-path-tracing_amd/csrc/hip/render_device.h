@@ -240,7 +240,8 @@ using TraceHbm = TraceCfg<true, true, true>;       // scenes walked from HBM
 
 // Called by the lanes whose ray is unfinished (tv.cur != kTravDone); the others of the wave sit it out.
 template <class TC>
-GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, float tnear, float tfar, Trav &tv, int stop_below, int search_frac, TraceCounters &tc) {
+GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, float tnear, float tfar, Trav &tv, int stop_below, int search_frac, TraceCounters &tc,
+                 bool any_hit = false) {     // any_hit: occlusion query, the walk ends at the first accepted primitive
     const float o[3] = {(float)org.x, (float)org.y, (float)org.z};
     const float d[3] = {(float)dir.x, (float)dir.y, (float)dir.z};
     float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
@@ -270,6 +271,7 @@ GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, flo
             if (cur < 0 && cur != kTravDone) {
                 test_leaf<TC::FLAT>(sv, tx, cur, o, d, tnear, tfar, best, tc);
                 trav_pop(tx, cur, sp);
+                if (any_hit && best.gid >= 0) cur = kTravDone;
             }
         } else if (cur >= 0) {
             if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
@@ -277,6 +279,7 @@ GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, flo
         } else if (cur != kTravDone) {
             test_leaf<TC::FLAT>(sv, tx, cur, o, d, tnear, tfar, best, tc);
             trav_pop(tx, cur, sp);
+            if (any_hit && best.gid >= 0) cur = kTravDone;
         }
     }
     tv.cur = cur; tv.sp = sp; tv.best = best;
@@ -292,6 +295,16 @@ GD bool intersect_ctx(const DevSceneView &sv, const TraceCtx &tx, const Ray &ray
     if (tv.best.gid < 0) return false;
     make_vertex(sv, tx.tris, tx.need_uv, ray, tv.best, 0.0, rd_spread, v);
     return true;
+}
+
+// occluded(), src/intersection.cpp:67-85: true if any primitive accepts the fp32 ray in [tnear, tfar).
+template <class TC>
+GD bool occluded_ctx(const DevSceneView &sv, const TraceCtx &tx, const Ray &ray, LaneCounters &lc, TraceCounters &tc) {
+    lc.rays++;
+    Trav tv;
+    trav_init(sv, tv, ray.tfar);
+    if (tv.cur != kTravDone) trav_run<TC>(sv, tx, ray.org, ray.dir, (float)ray.tnear, (float)ray.tfar, tv, 0, 0, tc, true);
+    return tv.best.gid >= 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -972,4 +985,6 @@ void launch_tile_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a,
 void launch_tile_phases_general(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
 void launch_eager(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, hipStream_t stream);
 void launch_tile_eager(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
+void launch_path(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, hipStream_t stream);
+void launch_tile_path(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
 } // namespace gdpt

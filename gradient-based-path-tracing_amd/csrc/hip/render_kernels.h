@@ -35,6 +35,7 @@ bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_material
 bool scene_fits_lds_wide(int num_nodes4, int num_prims, int num_tris, int num_materials, int wide_stack_need);
 
 // Doubles the `partials` buffer must hold for a band of `pixels` pixels at `spp`.
+void launch_path_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t stream);
 int render_log2_chunks(int spp, int force_log2k);
 size_t render_partials_doubles(int width, int rows, int spp, int force_log2k);
 

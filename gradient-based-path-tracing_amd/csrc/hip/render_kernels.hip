@@ -69,6 +69,37 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
     if (e != hipSuccess) throw std::runtime_error(std::string("render kernel launch failed: ") + hipGetErrorString(e));
 }
 
+// Integrator::Path (render_path.hip): img only.
+void launch_path_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t stream) {
+    gd::KernelArgs a{};
+    a.spp = rl.spp; a.row_begin = rl.row_begin; a.row_end = rl.row_end; a.max_depth = rl.max_depth;
+    a.img = rl.img; a.counters = rl.counters;
+    a.count = rl.count_traversal ? 1 : 0;
+    const int W = sv.cam.width, rows = rl.row_end - rl.row_begin;
+    if (W <= 0 || rows <= 0 || rl.spp <= 0) throw std::runtime_error("launch_path_render: empty image band or spp <= 0");
+    if (rl.rng_scheme == GDPT_RNG_TILE) {
+        int ntx = (W + 15) / 16, nty = (sv.cam.height + 15) / 16;
+        launch_tile_path(sv, a, dim3((unsigned)((ntx * nty + 63) / 64)), ntx, nty, stream);
+    } else if (rl.rng_scheme == GDPT_RNG_SAMPLE) {
+        // static mapping, K = 2^log2k lanes per pixel (enough lanes to fill the chip on small films)
+        long long pixels = (long long)W * rows;
+        int log2k = 0;
+        while ((1 << (log2k + 1)) <= rl.spp && log2k < 6 && (pixels << log2k) < (1LL << 19)) log2k++;
+        if (rl.force_log2k >= 0) { log2k = rl.force_log2k; while (log2k > 0 && (1 << log2k) > rl.spp) log2k--; }
+        a.log2k = log2k;
+        int ppb = gd::kBlock >> log2k;
+        a.tile_w = ppb >= 16 ? 16 : ppb;
+        a.tile_h = ppb / a.tile_w;
+        a.tiles_x = (W + a.tile_w - 1) / a.tile_w;
+        int tiles_y = (rows + a.tile_h - 1) / a.tile_h;
+        launch_path(sv, a, dim3((unsigned)(a.tiles_x * tiles_y)), stream);
+    } else {
+        throw std::runtime_error("launch_path_render: unknown rng_scheme");
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw std::runtime_error(std::string("path kernel launch failed: ") + hipGetErrorString(e));
+}
+
 int render_log2_chunks(int spp, int force_log2k) {
     int log2c = 0;
     while (log2c < 3 && (8 << log2c) <= spp) log2c++;          // 2^log2c <= spp/4, at most 8

@@ -682,7 +682,9 @@ struct Builder {
             } else if (c.name == "emitter") {
                 std::string type = c.attr("type");
                 if (type == "envmap") {
-                    // Integrator::GradPath never evaluates the environment (src/path_tracing.h:982-985): ignored.
+                    // Integrator::GradPath never evaluates the environment (src/path_tracing.h:982-985): ignored there;
+                    // the Path entry points refuse scenes that carry one.
+                    hs.desc.has_envmap = 1;
                 } else if (type == "point" || type == "directional") {
                     fail("emitter type '" + type + "' is outside the GradPath hot-path subset");
                 } else {

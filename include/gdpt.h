@@ -119,6 +119,8 @@ typedef struct GdptSceneDesc {
     const GdptLight *lights;
     const GdptImage *images;
     char output_filename[256]; /* film `filename`, default "image.exr" (src/parsers/parse_scene.cpp:15) */
+    int32_t has_envmap;        /* the XML holds an <emitter type="envmap">: ignored by GradPath, refused by the Path entry points */
+    int32_t _pad;
 } GdptSceneDesc;
 
 /* ---- render parameters ---- */
@@ -188,6 +190,14 @@ int gdpt_render(GdptScene *scene, const GdptRenderParams *params,
 int gdpt_render_device(GdptScene *scene, const GdptRenderParams *params,
                        double *d_img, double *d_cx0, double *d_cy0, double *d_cx1, double *d_cy1,
                        void *stream, GdptRenderStats *stats /* nullable */);
+
+/* ---- Integrator::Path (path_render, src/render.cpp:74-117 over path_tracing, src/path_tracing.h:13-348) ----
+ * Unidirectional path tracing with next-event estimation + MIS for scenes lit by area emitters (meshes, spheres):
+ * img = mean over spp of path_tracing(x, y). Same parameters, RNG schemes and stats as gdpt_render; scenes carrying
+ * an environment map are refused (error status), as are scenes without emitters. */
+int gdpt_path_render(GdptScene *scene, const GdptRenderParams *params, double *img, GdptRenderStats *stats /* nullable */);
+int gdpt_path_render_device(GdptScene *scene, const GdptRenderParams *params, double *d_img,
+                            void *stream, GdptRenderStats *stats /* nullable */);
 
 /* c=img; cx=cx0(x,y)+cx1(x-1,y); cy=cy0(x,y)+cy1(x,y-1)  (src/render.cpp:340-350). Device pointers. */
 int gdpt_assemble_device(int width, int height,

@@ -101,7 +101,8 @@ def gen_images():
         }
     # the reference's own renders (fp16 + ZIP EXR written by lajolla): coarse statistics for end-to-end sanity checks
     doc["reference_renders"] = {}
-    for rel in ("cbox_gdpt/cb_16.exr", "cbox_gdpt/cb_4.exr", "cbox_gdpt/cb_1.exr", "gdpt_renders/tmp_gdpt_0.04.exr"):
+    for rel in ("cbox_gdpt/cb_16.exr", "cbox_gdpt/cb_4.exr", "cbox_gdpt/cb_1.exr", "gdpt_renders/tmp_gdpt_0.04.exr",
+                "cbox_path/cb_1000.exr", "cbox_path/cb_256.exr", "cbox_path/cb_16.exr"):
         path = os.path.join(REF, rel)
         if not os.path.exists(path):
             continue

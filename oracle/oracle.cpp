@@ -130,6 +130,11 @@ struct OracleScene {
     std::vector<BNode> nodes;        // oracle's own BVH (median split) over prim ids
     std::vector<int> bvh_prims;
     mutable std::atomic<uint64_t> nodes_visited{0}, tris_tested{0};
+    // Integrator::Path: light selection table (src/scene.cpp:44-53) and per-mesh triangle tables of the emitters
+    // (init_sampling_dist, src/shapes/triangle_mesh.inl:60-75)
+    std::vector<Real> light_pmf, light_cdf;
+    struct MeshTable { std::vector<Real> pmf, cdf; Real total_area = 0; };
+    std::vector<MeshTable> mesh_tables;     // per shape (empty for non-emitters and spheres)
 };
 
 namespace {
@@ -1016,6 +1021,195 @@ void dct1(const std::vector<double> &tab, int n, const double *in, int stride, d
 } // namespace
 
 // ================================= C interface ====================================================
+namespace {
+
+// ---- Integrator::Path pieces -------------------------------------------------------------------
+void make_table_1d(const std::vector<Real> &f, std::vector<Real> &pmf, std::vector<Real> &cdf) { // src/table_dist.cpp:3-25
+    pmf = f;
+    cdf.assign(f.size() + 1, 0);
+    for (size_t i = 0; i < f.size(); i++) cdf[i + 1] = cdf[i] + pmf[i];
+    Real total = cdf.back();
+    if (total > 0) {
+        for (size_t i = 0; i < pmf.size(); i++) { pmf[i] /= total; cdf[i] /= total; }   // cdf.back() keeps the total
+    } else {
+        for (size_t i = 0; i < pmf.size(); i++) { pmf[i] = Real(1) / Real(pmf.size()); cdf[i] = Real(i) / Real(pmf.size()); }
+        cdf.back() = 1;
+    }
+}
+int table_sample(const std::vector<Real> &pmf, const std::vector<Real> &cdf, Real u) { // src/table_dist.cpp:27-33
+    int size = (int)pmf.size();
+    const Real *ptr = std::upper_bound(cdf.data(), cdf.data() + size + 1, u);
+    return std::min(std::max(int(ptr - cdf.data() - 1), 0), size - 1);
+}
+
+struct PointNormal { V3 position, normal; };
+
+PointNormal sample_point_on_shape(const OracleScene &sc, int shape_id, const V3 &ref_point, const V2 &uv, Real w) {
+    const GdptShape &sh = sc.desc.shapes[shape_id];
+    if (sh.type == GDPT_SHAPE_TRIMESH) {                                   // src/shapes/triangle_mesh.inl:24-50
+        const OracleScene::MeshTable &tb = sc.mesh_tables[(size_t)shape_id];
+        int tri = table_sample(tb.pmf, tb.cdf, w);
+        const int *ix = sh.indices + 3 * tri;
+        auto P = [&](int i) { return V3{sh.positions[3 * ix[i]], sh.positions[3 * ix[i] + 1], sh.positions[3 * ix[i] + 2]}; };
+        V3 v0 = P(0), v1 = P(1), v2 = P(2);
+        V3 e1 = v1 - v0, e2 = v2 - v0;
+        Real a = std::sqrt(std::min(std::max(uv.x, Real(0)), Real(1)));
+        Real b1 = 1 - a, b2 = a * uv.y;
+        V3 gn = normalize(cross(e1, e2));
+        if (sh.normals) {
+            auto N = [&](int i) { return V3{sh.normals[3 * ix[i]], sh.normals[3 * ix[i] + 1], sh.normals[3 * ix[i] + 2]}; };
+            V3 sn = normalize((1 - b1 - b2) * N(0) + b1 * N(1) + b2 * N(2));
+            if (dot(gn, sn) < 0) gn = -gn;
+        }
+        return {v0 + (e1 * b1) + (e2 * b2), gn};
+    }
+    // sphere, src/shapes/sphere.inl:161-205
+    V3 center{sh.center[0], sh.center[1], sh.center[2]};
+    Real r = sh.radius;
+    if (distance_squared(ref_point, center) < r * r) {
+        Real z = 1 - 2 * uv.x;
+        Real r_ = std::sqrt(std::fmax(Real(0), 1 - z * z));
+        Real phi = 2 * c_PI * uv.y;
+        V3 offset{r_ * std::cos(phi), r_ * std::sin(phi), z};
+        return {center + r * offset, offset};
+    }
+    V3 dir_to_center = normalize(center - ref_point);
+    Frame frame = make_frame(dir_to_center);
+    Real sin_elevation_max_sq = r * r / distance_squared(ref_point, center);
+    Real cos_elevation_max = std::sqrt(rmax(Real(0), 1 - sin_elevation_max_sq));
+    Real cos_elevation = (1 - uv.x) + uv.x * cos_elevation_max;
+    Real sin_elevation = std::sqrt(rmax(Real(0), 1 - cos_elevation * cos_elevation));
+    Real azimuth = uv.y * 2 * c_PI;
+    Real dc = std::sqrt(distance_squared(ref_point, center));
+    Real ds = dc * cos_elevation - std::sqrt(rmax(Real(0), r * r - dc * dc * sin_elevation * sin_elevation));
+    Real cos_alpha = (dc * dc + r * r - ds * ds) / (2 * dc * r);
+    Real sin_alpha = std::sqrt(rmax(Real(0), 1 - cos_alpha * cos_alpha));
+    V3 n_on_sphere = -to_world(frame, V3{sin_alpha * std::cos(azimuth), sin_alpha * std::sin(azimuth), cos_alpha});
+    return {r * n_on_sphere + center, n_on_sphere};
+}
+
+Real surface_area(const OracleScene &sc, int shape_id) {
+    const GdptShape &sh = sc.desc.shapes[shape_id];
+    if (sh.type == GDPT_SHAPE_TRIMESH) return sc.mesh_tables[(size_t)shape_id].total_area;
+    return 4 * c_PI * sh.radius * sh.radius;
+}
+
+Real pdf_point_on_shape(const OracleScene &sc, int shape_id, const PointNormal &pt, const V3 &ref_point) {
+    const GdptShape &sh = sc.desc.shapes[shape_id];
+    if (sh.type == GDPT_SHAPE_TRIMESH) return 1 / surface_area(sc, shape_id);      // triangle_mesh.inl:56-58
+    V3 center{sh.center[0], sh.center[1], sh.center[2]};                            // sphere.inl:211-228
+    Real r = sh.radius;
+    if (distance_squared(ref_point, center) < r * r) return 1 / surface_area(sc, shape_id);
+    Real sin_elevation_max_sq = r * r / distance_squared(ref_point, center);
+    Real cos_elevation_max = std::sqrt(rmax(Real(0), 1 - sin_elevation_max_sq));
+    Real pdf_solid_angle = 1 / (2 * c_PI * (1 - cos_elevation_max));
+    V3 dir = normalize(pt.position - ref_point);
+    return pdf_solid_angle * std::fabs(dot(pt.normal, dir)) / distance_squared(ref_point, pt.position);
+}
+
+bool occluded(const OracleScene &sc, const Ray &ray) {                              // src/intersection.cpp:67-85
+    float o[3] = {(float)ray.org.x, (float)ray.org.y, (float)ray.org.z};
+    float d[3] = {(float)ray.dir.x, (float)ray.dir.y, (float)ray.dir.z};
+    return closest_hit(sc, o, d, (float)ray.tnear, (float)ray.tfar).valid;
+}
+
+// path_tracing, src/path_tracing.h:13-348, scenes without an environment map.
+V3 path_sample(const OracleScene &sc, int x, int y, Pcg &rng, int *bounces_out, int *shadow_out, int *rays_out = nullptr) {
+    const GdptSceneDesc &D = sc.desc;
+    int w = D.camera.width, h = D.camera.height;
+    int bounces = 0, shadows = 0, rays = 1;      // rays: closest-hit + occlusion queries actually issued
+    if (bounces_out) *bounces_out = 0;
+    if (shadow_out) *shadow_out = 0;
+    if (rays_out) *rays_out = 1;
+    // :21-22 — constructor arguments; evaluated left to right by the compiler the reference was developed with
+    Real rx = pcg_real(rng);
+    Real ry = pcg_real(rng);
+    V2 screen_pos{(x + rx) / w, (y + ry) / h};
+    Ray ray = sample_primary(D.camera, screen_pos);
+    Real rd_spread = Real(0.25) / Real(std::max(w, h));                              // init_ray_differential, src/ray.h:33-35
+    Vertex vertex;
+    if (!intersect(sc, ray, 0, rd_spread, &vertex)) return {0, 0, 0};               // :31-43 (no envmap)
+    V3 radiance{0, 0, 0};
+    V3 throughput{1, 1, 1};
+    Real eta_scale = 1;
+    if (is_light(sc, vertex.shape_id)) radiance = radiance + throughput * emission(sc, vertex, -ray.dir);   // :76-79
+    int max_depth = D.max_depth;
+    Real shadow_eps = sc.isect_eps;                                                 // get_shadow_epsilon == get_intersection_epsilon (src/scene.h:100-106)
+    for (int num_vertices = 3; max_depth == -1 || num_vertices <= max_depth + 1; num_vertices++) {
+        bounces++;
+        const GdptMaterial &mat = D.materials[vertex.material_id];
+        // ---- next-event estimation, :116-175
+        V2 light_uv; light_uv.x = pcg_real(rng); light_uv.y = pcg_real(rng);
+        Real light_w = pcg_real(rng);
+        Real shape_w = pcg_real(rng);
+        int light_id = table_sample(sc.light_pmf, sc.light_cdf, light_w);
+        const GdptLight &light = D.lights[light_id];
+        PointNormal pl = sample_point_on_shape(sc, light.shape_id, vertex.position, light_uv, shape_w);
+        V3 C1{0, 0, 0};
+        Real w1 = 0;
+        {
+            Real G = 0;
+            V3 dir_light = normalize(pl.position - vertex.position);
+            Real dist = std::sqrt(distance_squared(pl.position, vertex.position));
+            Ray shadow_ray{vertex.position, dir_light, shadow_eps, (1 - shadow_eps) * dist};
+            shadows++; rays++;
+            if (!occluded(sc, shadow_ray))
+                G = rmax(-dot(dir_light, pl.normal), Real(0)) / distance_squared(pl.position, vertex.position);
+            Real p1 = sc.light_pmf[(size_t)light_id] * pdf_point_on_shape(sc, light.shape_id, pl, vertex.position);
+            if (G > 0 && p1 > 0) {
+                V3 dir_view = -ray.dir;
+                V3 f = bsdf_eval(sc, mat, dir_view, dir_light, vertex);
+                V3 L = (dot(pl.normal, -dir_light) <= 0) ? V3{0, 0, 0} : V3{light.intensity[0], light.intensity[1], light.intensity[2]};
+                C1 = G * f * L;
+                Real p2 = bsdf_pdf(sc, mat, dir_view, dir_light, vertex);
+                p2 *= G;
+                w1 = (p1 * p1) / (p1 * p1 + p2 * p2);
+                C1 = C1 / p1;
+            }
+        }
+        radiance = radiance + throughput * C1 * w1;
+        // ---- BSDF sampling, :186-230
+        V3 dir_view = -ray.dir;
+        V2 ruv; ruv.x = pcg_real(rng); ruv.y = pcg_real(rng);
+        Real rw = pcg_real(rng);
+        BsdfSample bs;
+        if (!bsdf_sample(sc, mat, dir_view, vertex, ruv, rw, &bs)) break;           // :200-203
+        V3 dir_bsdf = bs.dir_out;
+        if (bs.eta != 0) eta_scale /= (bs.eta * bs.eta);                            // ray_diff.spread only feeds envmap lookups
+        Ray bsdf_ray{vertex.position, dir_bsdf, sc.isect_eps, std::numeric_limits<Real>::infinity()};
+        Vertex bsdf_vertex;
+        bool hit = intersect(sc, bsdf_ray, 0, 0, &bsdf_vertex);
+        rays++;
+        Real G = 1;
+        if (hit) G = std::fabs(dot(dir_bsdf, bsdf_vertex.geometric_normal)) / distance_squared(bsdf_vertex.position, vertex.position);
+        V3 f = bsdf_eval(sc, mat, dir_view, dir_bsdf, vertex);
+        Real p2 = bsdf_pdf(sc, mat, dir_view, dir_bsdf, vertex);
+        if (p2 <= 0) break;                                                         // :263-266
+        p2 *= G;
+        if (hit && is_light(sc, bsdf_vertex.shape_id)) {                            // :286-306: added WITHOUT the MIS weight w2
+            V3 L = emission(sc, bsdf_vertex, -dir_bsdf);
+            V3 C2 = G * f * L;
+            C2 = C2 / p2;
+            radiance = radiance + throughput * C2;
+        }
+        if (!hit) break;                                                            // :327-329
+        Real rr_prob = 1;
+        if (num_vertices - 1 >= D.rr_depth) {                                       // :333-340
+            rr_prob = rmin(maxc((1 / eta_scale) * throughput), Real(0.95));
+            if (pcg_real(rng) > rr_prob) break;
+        }
+        ray = bsdf_ray;
+        vertex = bsdf_vertex;
+        throughput = throughput * (G * f) / (p2 * rr_prob);                          // :344
+    }
+    if (bounces_out) *bounces_out = bounces;
+    if (shadow_out) *shadow_out = shadows;
+    if (rays_out) *rays_out = rays;
+    return radiance;
+}
+
+} // namespace
+
 extern "C" {
 
 OracleScene *oracle_scene_create(const GdptSceneDesc *desc, int use_bvh) {
@@ -1064,6 +1258,31 @@ OracleScene *oracle_scene_create(const GdptSceneDesc *desc, int use_bvh) {
             for (int k = 0; k < 3; k++) cent[3 * g + k] = 0.5f * (bb[6 * g + k] + bb[6 * g + 3 + k]);
         }
         if (n > 0) build_node(*sc, ids, 0, n, cent, bb);
+    }
+    // emitter sampling tables (Integrator::Path): init_sampling_dist per emitter mesh, then the light power table
+    sc->mesh_tables.resize((size_t)desc->num_shapes);
+    for (int sidx = 0; sidx < desc->num_shapes; sidx++) {
+        const GdptShape &sh = desc->shapes[sidx];
+        if (sh.type != GDPT_SHAPE_TRIMESH || sh.area_light_id < 0) continue;
+        std::vector<Real> areas((size_t)sh.num_triangles, Real(0));
+        Real total = 0;
+        for (int t = 0; t < sh.num_triangles; t++) {
+            const int *ix = sh.indices + 3 * t;
+            auto P = [&](int i) { return V3{sh.positions[3 * ix[i]], sh.positions[3 * ix[i] + 1], sh.positions[3 * ix[i] + 2]}; };
+            V3 v0 = P(0), e1 = P(1) - v0, e2 = P(2) - v0;
+            areas[(size_t)t] = length(cross(e1, e2)) / 2;
+            total += areas[(size_t)t];
+        }
+        make_table_1d(areas, sc->mesh_tables[(size_t)sidx].pmf, sc->mesh_tables[(size_t)sidx].cdf);
+        sc->mesh_tables[(size_t)sidx].total_area = total;
+    }
+    {
+        std::vector<Real> power((size_t)desc->num_lights);
+        for (int l = 0; l < desc->num_lights; l++) {                       // light_power, src/lights/diffuse_area_light.inl:1-3
+            const GdptLight &lt = desc->lights[l];
+            power[(size_t)l] = luminance(V3{lt.intensity[0], lt.intensity[1], lt.intensity[2]}) * surface_area(*sc, lt.shape_id) * c_PI;
+        }
+        if (!power.empty()) make_table_1d(power, sc->light_pmf, sc->light_cdf);
     }
     return sc;
 }
@@ -1212,6 +1431,90 @@ int oracle_render(const OracleScene *s, int spp, int rng_scheme, int row_begin, 
     if (stats) {
         stats->samples = a_samples; stats->rays = a_rays; stats->bounces = a_bounces; stats->primary_misses = a_miss;
         stats->x0_valid_initial = a_x0; stats->nonfinite_samples = a_nonfinite;
+        stats->nodes_visited = sc.nodes_visited; stats->tris_tested = sc.tris_tested;
+        stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return 0;
+}
+
+void oracle_light_table(const OracleScene *s, double *pmf, double *cdf) {
+    for (size_t i = 0; i < s->light_pmf.size(); i++) pmf[i] = s->light_pmf[i];
+    for (size_t i = 0; i < s->light_cdf.size(); i++) cdf[i] = s->light_cdf[i];
+}
+void oracle_sample_point_on_shape(const OracleScene *s, int shape_id, const double ref_point[3], const double uv[2], double w, double out[6]) {
+    PointNormal p = sample_point_on_shape(*s, shape_id, V3{ref_point[0], ref_point[1], ref_point[2]}, V2{uv[0], uv[1]}, w);
+    for (int k = 0; k < 3; k++) { out[k] = p.position[k]; out[3 + k] = p.normal[k]; }
+}
+double oracle_pdf_point_on_shape(const OracleScene *s, int shape_id, const double point[3], const double normal[3], const double ref_point[3]) {
+    PointNormal p{V3{point[0], point[1], point[2]}, V3{normal[0], normal[1], normal[2]}};
+    return pdf_point_on_shape(*s, shape_id, p, V3{ref_point[0], ref_point[1], ref_point[2]});
+}
+int oracle_occluded(const OracleScene *s, const double org[3], const double dir[3], double tnear, double tfar) {
+    Ray r{V3{org[0], org[1], org[2]}, V3{dir[0], dir[1], dir[2]}, tnear, tfar};
+    return occluded(*s, r) ? 1 : 0;
+}
+void oracle_path_sample(const OracleScene *s, int x, int y, uint64_t *state, uint64_t inc, double radiance[3], int32_t *bounces, int32_t *shadow_rays) {
+    Pcg rng{*state, inc};
+    int b = 0, sh = 0;
+    V3 r = path_sample(*s, x, y, rng, &b, &sh);
+    *state = rng.state;
+    radiance[0] = r.x; radiance[1] = r.y; radiance[2] = r.z;
+    if (bounces) *bounces = b;
+    if (shadow_rays) *shadow_rays = sh;
+}
+
+int oracle_path_render(const OracleScene *s, int spp, int rng_scheme, int row_begin, int row_end, int threads,
+                       double *img, OracleStats *stats) {
+    const OracleScene &sc = *s;
+    if (sc.desc.has_envmap || sc.desc.num_lights <= 0) return 2;
+    int w = sc.desc.camera.width, h = sc.desc.camera.height;
+    if (spp <= 0) spp = sc.desc.samples_per_pixel;
+    if (row_begin == 0 && row_end == 0) row_end = h;
+    if (rng_scheme != GDPT_RNG_TILE && rng_scheme != GDPT_RNG_SAMPLE) return 1;
+    constexpr int tile_size = 16;                                              // src/render.cpp:83
+    int ntx = (w + tile_size - 1) / tile_size, nty = (h + tile_size - 1) / tile_size;
+    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    if (threads <= 0) threads = 1;
+    sc.nodes_visited = 0; sc.tris_tested = 0;
+    std::atomic<int> next_tile{0};
+    std::atomic<uint64_t> a_samples{0}, a_rays{0}, a_bounces{0}, a_nonfinite{0};
+    auto t0 = std::chrono::steady_clock::now();
+    auto worker = [&]() {
+        uint64_t n_samples = 0, n_rays = 0, n_bounces = 0, n_nf = 0;
+        for (;;) {
+            int tile = next_tile.fetch_add(1);
+            if (tile >= ntx * nty) break;
+            int tx = tile % ntx, ty = tile / ntx;
+            Pcg rng = pcg_init((uint64_t)(ty * ntx + tx));                     // src/render.cpp:94
+            int x0 = tx * tile_size, x1 = std::min(x0 + tile_size, w);
+            int y0 = ty * tile_size, y1 = std::min(y0 + tile_size, h);
+            for (int y = y0; y < y1; y++) {
+                if (y < row_begin || y >= row_end) continue;
+                for (int x = x0; x < x1; x++) {
+                    V3 radiance{0, 0, 0};
+                    for (int sidx = 0; sidx < spp; sidx++) {
+                        if (rng_scheme == GDPT_RNG_SAMPLE) rng = pcg_init(((uint64_t)y * w + x) * (uint64_t)spp + (uint64_t)sidx);
+                        int b = 0, sh = 0, nr = 0;
+                        V3 r = path_sample(sc, x, y, rng, &b, &sh, &nr);
+                        radiance = radiance + r;                               // src/render.cpp:107-109
+                        n_samples++; n_bounces += (uint64_t)b; n_rays += (uint64_t)nr;
+                        if (!(std::isfinite(r.x) && std::isfinite(r.y) && std::isfinite(r.z))) n_nf++;
+                    }
+                    V3 px = radiance / Real(spp);                              // :110
+                    size_t i = ((size_t)y * w + x) * 3;
+                    for (int c = 0; c < 3; c++) img[i + c] += px[c];
+                }
+            }
+        }
+        a_samples += n_samples; a_rays += n_rays; a_bounces += n_bounces; a_nonfinite += n_nf;
+    };
+    std::vector<std::thread> pool;
+    for (int i = 1; i < threads; i++) pool.emplace_back(worker);
+    worker();
+    for (auto &t : pool) t.join();
+    if (stats) {
+        stats->samples = a_samples; stats->rays = a_rays; stats->bounces = a_bounces; stats->primary_misses = 0;
+        stats->x0_valid_initial = 0; stats->nonfinite_samples = a_nonfinite;
         stats->nodes_visited = sc.nodes_visited; stats->tris_tested = sc.tris_tested;
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }

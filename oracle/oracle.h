@@ -79,6 +79,23 @@ void oracle_grad_sample(const OracleScene *s, int x, int y, uint64_t *state, uin
 int oracle_render(const OracleScene *s, int spp, int rng_scheme, int row_begin, int row_end, int threads,
                   double *img, double *cx0, double *cy0, double *cx1, double *cy1, OracleStats *stats);
 
+/* ---- Integrator::Path: path_tracing with next-event estimation + MIS, area lights only ---- */
+/* Light selection table (src/scene.cpp:44-66): pmf[num_lights], cdf[num_lights+1]. */
+void oracle_light_table(const OracleScene *s, double *pmf, double *cdf);
+/* sample_point_on_shape / pdf_point_on_shape (src/shapes/triangle_mesh.inl:24-58, src/shapes/sphere.inl:161-230).
+ * out: position[3], normal[3]. */
+void oracle_sample_point_on_shape(const OracleScene *s, int shape_id, const double ref_point[3], const double uv[2], double w, double out[6]);
+double oracle_pdf_point_on_shape(const OracleScene *s, int shape_id, const double point[3], const double normal[3], const double ref_point[3]);
+/* occluded(), src/intersection.cpp:67-85: any primitive accepting the fp32 ray in [tnear, tfar). */
+int oracle_occluded(const OracleScene *s, const double org[3], const double dir[3], double tnear, double tfar);
+/* One path_tracing call (src/path_tracing.h:13-348) on pixel (x,y); advances the RNG. The two sub-pixel numbers are
+ * drawn x first (the left-to-right order of the compiler the reference was developed with). */
+void oracle_path_sample(const OracleScene *s, int x, int y, uint64_t *state, uint64_t inc, double radiance[3], int32_t *bounces, int32_t *shadow_rays);
+/* path_render tile loop (src/render.cpp:74-117): img = mean over spp of path_tracing. W*H*3 doubles, caller-zeroed.
+ * Returns non-zero for scenes with an environment map (not restated). */
+int oracle_path_render(const OracleScene *s, int spp, int rng_scheme, int row_begin, int row_end, int threads,
+                       double *img, OracleStats *stats);
+
 /* gradient assembly, src/render.cpp:340-350 */
 void oracle_assemble(int w, int h, const double *img, const double *cx0, const double *cy0,
                      const double *cx1, const double *cy1, double *c, double *cx, double *cy);

@@ -73,6 +73,16 @@ def lib():
         L.oracle_grad_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(OracleSampleRecord)]
         L.oracle_render.restype = C.c_int
         L.oracle_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, C.POINTER(OracleStats)]
+        L.oracle_light_table.argtypes = [C.c_void_p, dp, dp]
+        L.oracle_sample_point_on_shape.argtypes = [C.c_void_p, C.c_int, dp, dp, C.c_double, dp]
+        L.oracle_pdf_point_on_shape.restype = C.c_double
+        L.oracle_pdf_point_on_shape.argtypes = [C.c_void_p, C.c_int, dp, dp, dp]
+        L.oracle_occluded.restype = C.c_int
+        L.oracle_occluded.argtypes = [C.c_void_p, dp, dp, C.c_double, C.c_double]
+        L.oracle_path_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_uint64, dp,
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.oracle_path_render.restype = C.c_int
+        L.oracle_path_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, C.POINTER(OracleStats)]
         L.oracle_assemble.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp]
         L.oracle_poisson_dct.argtypes = [C.c_int, C.c_int, dp, dp, dp, C.c_double, dp]
         _LIB = L
@@ -164,6 +174,47 @@ class OracleScene:
         if rc != 0:
             raise RuntimeError("oracle_render failed")
         return bufs, st
+
+
+def _path_methods():
+    """Integrator::Path additions to OracleScene (kept together; see oracle.h)."""
+    def light_table(self, num_lights):
+        pmf, cdf = np.zeros(num_lights), np.zeros(num_lights + 1)
+        lib().oracle_light_table(self.handle, _dp(pmf), _dp(cdf))
+        return pmf, cdf
+
+    def sample_point_on_shape(self, shape_id, ref_point, uv, w):
+        out = np.zeros(6)
+        lib().oracle_sample_point_on_shape(self.handle, int(shape_id), _vec(ref_point), _vec(uv), float(w), _dp(out))
+        return out[:3].copy(), out[3:].copy()
+
+    def pdf_point_on_shape(self, shape_id, point, normal, ref_point):
+        return lib().oracle_pdf_point_on_shape(self.handle, int(shape_id), _vec(point), _vec(normal), _vec(ref_point))
+
+    def occluded(self, org, dirv, tnear, tfar):
+        return bool(lib().oracle_occluded(self.handle, _vec(org), _vec(dirv), float(tnear), float(tfar)))
+
+    def path_sample(self, x, y, state, inc):
+        st = C.c_uint64(state)
+        rad = np.zeros(3)
+        b, sh = C.c_int32(), C.c_int32()
+        lib().oracle_path_sample(self.handle, int(x), int(y), C.byref(st), C.c_uint64(inc), _dp(rad), C.byref(b), C.byref(sh))
+        return rad, st.value, b.value, sh.value
+
+    def path_render(self, spp, rng_scheme, rows=(0, 0), threads=0):
+        """path_render (src/render.cpp:74-117): HxWx3 image + OracleStats."""
+        img = np.zeros((self.height, self.width, 3))
+        st = OracleStats()
+        rc = lib().oracle_path_render(self.handle, int(spp), int(rng_scheme), int(rows[0]), int(rows[1]), int(threads), _dp(img), C.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"oracle_path_render failed ({rc}): scenes with an environment map / without lights are not restated")
+        return img, st
+
+    for f in (light_table, sample_point_on_shape, pdf_point_on_shape, occluded, path_sample, path_render):
+        setattr(OracleScene, f.__name__, f)
+
+
+_path_methods()
 
 
 def pcg_init(stream):

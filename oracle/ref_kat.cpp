@@ -15,8 +15,10 @@
 #include "parsers/parse_obj.h"
 #include "parsers/shape_utils.h"
 #include "pcg.h"
+#include "point_and_normal.h"
 #include "shape.h"
 #include "spectrum.h"
+#include "table_dist.h"
 #include "texture.h"
 #include "transform.h"
 
@@ -28,6 +30,7 @@
 
 // defined in the reference's shape.cpp (via shapes/sphere.inl), not declared in a header
 void sphere_intersect_func(const RTCIntersectFunctionNArguments *args);
+void sphere_occluded_func(const RTCOccludedFunctionNArguments *args);
 
 static uint64_t lcg_state = 0x9E3779B97F4A7C15ULL;
 static double urand() {   // own deterministic generator for test inputs
@@ -328,6 +331,86 @@ static void emit_obj(const std::string &scene_dir) {
     printf("],");
 }
 
+// Emitter sampling of Integrator::Path: table distributions (src/table_dist.cpp),
+// sample_point_on_shape / pdf_point_on_shape / surface_area for a triangle mesh (the cbox luminaire under its scene
+// transform, and the large box with vertex normals under a general transform) and a sphere, and the sphere's
+// occlusion callback (src/shapes/sphere.inl:108-146).
+static void emit_light_sampling(const std::string &scene_dir) {
+    printf("\"light_sampling\":{");
+    {   // TableDist1D
+        std::vector<Real> f = {0.5, 0.0, 2.25, 1.0, 0.0, 3.5};
+        TableDist1D t = make_table_dist_1d(f);
+        printf("\"table\":{\"f\":[0.5,0.0,2.25,1.0,0.0,3.5],\"pmf\":[");
+        for (size_t i = 0; i < t.pmf.size(); i++) printf("%s%.17g", i ? "," : "", t.pmf[i]);
+        printf("],\"cdf\":[");
+        for (size_t i = 0; i < t.cdf.size(); i++) printf("%s%.17g", i ? "," : "", t.cdf[i]);
+        printf("],\"samples\":[");
+        const double us[] = {0.0, 0.0689655172413793, 0.07, 0.3, 0.379310344827586, 0.5, 0.5172413793103449, 0.52, 0.9999999999, 0.25};
+        for (int i = 0; i < 10; i++) printf("%s[%.17g,%d]", i ? "," : "", us[i], sample(t, us[i]));
+        printf("]},");
+    }
+    printf("\"meshes\":[");
+    for (int m = 0; m < 2; m++) {
+        Matrix4x4 to_world = (m == 0) ? translate(Vector3{0.0, (double)-0.5f, 0.0}) : rotate(30.0, Vector3{0.2, 1.0, 0.1}) * scale(Vector3{1.5, 1.0, 0.5});
+        const char *file = m == 0 ? "cbox_luminaire.obj" : "cbox_largebox.obj";
+        TriangleMesh mesh = parse_obj(scene_dir + "/meshes/" + file, to_world);
+        if (m == 1) mesh.normals = compute_normal(mesh.positions, mesh.indices);      // exercise the shading-side flip
+        Shape shape = mesh;
+        init_sampling_dist(shape);
+        printf("%s{\"file\":\"%s\",\"variant\":%d,\"with_normals\":%d,\"area\":%.17g,\"cases\":[", m ? "," : "", file, m == 0 ? 1 : 2, m, surface_area(shape));
+        for (int i = 0; i < 16; i++) {
+            Vector3 ref = Vector3{600 * urand(), 600 * urand(), 600 * urand()};
+            Vector2 uv{urand(), urand()};
+            if (i == 3) uv = Vector2{0.0, 0.0};
+            if (i == 4) uv = Vector2{1.0, 1.0};
+            Real w = urand();
+            PointAndNormal pn = sample_point_on_shape(shape, ref, uv, w);
+            Real pdf = pdf_point_on_shape(shape, pn, ref);
+            printf("%s{\"ref\":[%.17g,%.17g,%.17g],\"uv\":[%.17g,%.17g],\"w\":%.17g,\"position\":[%.17g,%.17g,%.17g],\"normal\":[%.17g,%.17g,%.17g],\"pdf\":%.17g}",
+                   i ? "," : "", ref.x, ref.y, ref.z, uv.x, uv.y, w, pn.position.x, pn.position.y, pn.position.z, pn.normal.x, pn.normal.y, pn.normal.z, pdf);
+        }
+        printf("]}");
+    }
+    printf("],\"sphere\":{\"center\":[1.0,-2.0,0.5],\"radius\":2.5,");
+    {
+        Sphere sp{{}, Vector3{1.0, -2.0, 0.5}, 2.5};
+        Shape shape = sp;
+        printf("\"area\":%.17g,\"cases\":[", surface_area(shape));
+        for (int i = 0; i < 20; i++) {
+            Vector3 ref = (i % 4 == 3) ? Vector3{1.0 + 2.0 * (urand() - 0.5), -2.0 + 2.0 * (urand() - 0.5), 0.5 + 2.0 * (urand() - 0.5)}   // inside
+                                       : Vector3{1.0, -2.0, 0.5} + (3.0 + 20.0 * urand()) * rand_dir();
+            Vector2 uv{urand(), urand()};
+            if (i == 5) uv = Vector2{0.0, 0.25};
+            if (i == 6) uv = Vector2{1.0, 0.75};
+            PointAndNormal pn = sample_point_on_shape(shape, ref, uv, urand());
+            Real pdf = pdf_point_on_shape(shape, pn, ref);
+            printf("%s{\"ref\":[%.17g,%.17g,%.17g],\"uv\":[%.17g,%.17g],\"position\":[%.17g,%.17g,%.17g],\"normal\":[%.17g,%.17g,%.17g],\"pdf\":%.17g}",
+                   i ? "," : "", ref.x, ref.y, ref.z, uv.x, uv.y, pn.position.x, pn.position.y, pn.position.z, pn.normal.x, pn.normal.y, pn.normal.z, pdf);
+        }
+        printf("],\"occluded\":[");
+        for (int i = 0; i < 16; i++) {
+            RTCRay ray;
+            Vector3 o = Vector3{10 * (urand() - 0.5), 10 * (urand() - 0.5), 10 * (urand() - 0.5)};
+            Vector3 d = (i % 2 == 0) ? normalize(sp.position - o + 2.0 * rand_dir()) : rand_dir();
+            ray.org_x = (float)o.x; ray.org_y = (float)o.y; ray.org_z = (float)o.z;
+            ray.dir_x = (float)d.x; ray.dir_y = (float)d.y; ray.dir_z = (float)d.z;
+            ray.tnear = (i % 5 == 0) ? 0.01f : 0.0f;
+            ray.tfar = (i % 3 == 0) ? (float)(0.5 + 6.0 * urand()) : std::numeric_limits<float>::infinity();
+            ray.time = 0; ray.mask = (unsigned)-1; ray.id = 0; ray.flags = 0;
+            float tfar0 = ray.tfar;
+            int valid = -1;
+            RTCOccludedFunctionNArguments args;
+            args.valid = &valid; args.geometryUserPtr = (void *)&sp; args.primID = 0; args.context = nullptr;
+            args.ray = (RTCRayN *)&ray; args.N = 1; args.geomID = 7;
+            sphere_occluded_func(&args);
+            printf("%s{\"org\":[%.9g,%.9g,%.9g],\"dir\":[%.9g,%.9g,%.9g],\"tnear\":%.9g,\"tfar\":%s%.9g%s,\"occluded\":%d}", i ? "," : "",
+                   ray.org_x, ray.org_y, ray.org_z, ray.dir_x, ray.dir_y, ray.dir_z, ray.tnear,
+                   std::isinf(tfar0) ? "\"" : "", std::isinf(tfar0) ? 0.0 : tfar0, std::isinf(tfar0) ? "inf\"" : "", ray.tfar < 0 ? 1 : 0);
+        }
+        printf("]}},");
+    }
+}
+
 // spectra file: one spectrum per line, "w0 v0 w1 v1 ..." (already rounded through fp32 by the generator script)
 static void emit_spectra(const std::string &path) {
     printf("\"spectra\":[");
@@ -360,6 +443,7 @@ int main(int argc, char **argv) {
     emit_shading_info();
     emit_sphere_hits();
     emit_obj(argv[1]);
+    emit_light_sampling(argv[1]);
     emit_spectra(argv[2]);
     printf("\"generator\":\"oracle/ref_kat.cpp linked against the reference sources (see oracle/Makefile)\"}\n");
     return 0;
