@@ -51,8 +51,8 @@ int main(int argc, char *argv[]) {
             std::cerr << "terminate: " << gdpt_last_error() << std::endl;   // the reference dies on an uncaught fl_exception
             return 134;
         }
-        if (desc->integrator != GDPT_INTEGRATOR_GRADPATH) {
-            std::cerr << "terminate: this build implements Integrator::GradPath only (scene asks for another integrator)" << std::endl;
+        if (desc->integrator != GDPT_INTEGRATOR_GRADPATH && desc->integrator != GDPT_INTEGRATOR_PATH) {
+            std::cerr << "terminate: this build implements Integrator::GradPath and Integrator::Path (scene asks for another integrator)" << std::endl;
             return 134;
         }
         GdptScene *scene = nullptr;
@@ -69,7 +69,11 @@ int main(int argc, char *argv[]) {
         p.spp = spp; p.rng_scheme = rng;
         GdptRenderStats rs{};
         GdptPoissonStats ps{};
-        if (gdpt_gradient_path_render(scene, &p, alpha, image.data(), nullptr, nullptr, nullptr, nullptr, nullptr, &rs, &ps) != 0) {
+        // render() dispatches on the integrator (src/render.cpp:374-392)
+        const int rc = (desc->integrator == GDPT_INTEGRATOR_PATH)
+                           ? gdpt_path_render(scene, &p, image.data(), &rs)
+                           : gdpt_gradient_path_render(scene, &p, alpha, image.data(), nullptr, nullptr, nullptr, nullptr, nullptr, &rs, &ps);
+        if (rc != 0) {
             std::cerr << "terminate: " << gdpt_last_error() << std::endl;
             return 134;
         }

@@ -161,3 +161,19 @@ def test_gpu_path_refuses_environment_maps(G):
     sd = G.parse_scene(os.path.join(ROOT, "scenes", "disney_bsdf_test", "disney_bsdf.xml"))
     with pytest.raises(G.GdptError, match="environment"):
         G.Scene(sd).path_render(1)
+
+
+@pytest.mark.gpu
+def test_gpu_cli_renders_path_scenes(G, scene_tmp, tmp_path):
+    """lajolla dispatches on the scene's integrator like render() (src/render.cpp:374-392) and writes an EXR the
+    build's reader (and the reference's, see test_image_io.py) can load."""
+    import subprocess
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=48, height=32, integrator="path")
+    exe = os.path.join(ROOT, "gradient-based-path-tracing_amd", "lajolla")
+    out = tmp_path / "p.exr"
+    r = subprocess.run([exe, "-o", str(out), "--spp", "4", xml], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    img = G.imread(str(out), 3)
+    want, _ = G.Scene(G.parse_scene(xml)).path_render(4, G.RNG_SAMPLE)
+    assert img.shape == (32, 48, 3)
+    assert np.allclose(img, want, rtol=2e-3, atol=1e-4)             # fp16 storage
