@@ -178,7 +178,7 @@ void read_exr_rgb(const std::string &filename, int *width, int *height, std::vec
     if (!ifs) throw std::runtime_error("Failure when loading image: " + filename);
     std::vector<unsigned char> f((std::istreambuf_iterator<char>(ifs)), std::istreambuf_iterator<char>());
     size_t pos = 0;
-    auto need = [&](size_t n) { if (pos + n > f.size()) throw std::runtime_error("Failure when loading image: truncated " + filename); };
+    auto need = [&](size_t n) { if (n > f.size() || pos > f.size() - n) throw std::runtime_error("Failure when loading image: truncated " + filename); };
     auto rd32 = [&]() { need(4); uint32_t v = f[pos] | (f[pos + 1] << 8) | (f[pos + 2] << 16) | ((uint32_t)f[pos + 3] << 24); pos += 4; return v; };
     auto rdstr = [&]() { std::string s; for (;;) { need(1); char c = (char)f[pos++]; if (!c) break; s.push_back(c); } return s; };
     if (rd32() != 20000630u) throw std::runtime_error("Failure when loading image: not an OpenEXR file: " + filename);
@@ -196,25 +196,30 @@ void read_exr_rgb(const std::string &filename, int *width, int *height, std::vec
         const size_t vpos = pos;
         if (name == "channels") {
             size_t p = vpos;
-            while (p < vpos + n && f[p]) {
+            const size_t vend = vpos + n;
+            while (p < vend && f[p]) {
                 Chan c;
-                while (f[p]) c.name.push_back((char)f[p++]);
+                while (p < vend && f[p]) c.name.push_back((char)f[p++]);
                 p++;
+                if (p + 16 > vend) throw std::runtime_error("Failure when loading image: bad OpenEXR channel list: " + filename);
                 c.type = (int)(f[p] | (f[p + 1] << 8));
+                if (c.type < 0 || c.type > 2) throw std::runtime_error("Failure when loading image: bad OpenEXR pixel type: " + filename);
                 p += 4 + 4;                               // pixel type, pLinear + reserved
                 uint32_t xs = f[p] | (f[p + 1] << 8), ys = f[p + 4] | (f[p + 5] << 8);
                 p += 8;
                 if (xs != 1 || ys != 1) throw std::runtime_error("Unsupported image format: subsampled OpenEXR channel: " + filename);
                 chans.push_back(c);
             }
-        } else if (name == "compression") compression = f[vpos];
-        else if (name == "dataWindow") { pos = vpos; x0 = (int)rd32(); y0 = (int)rd32(); x1 = (int)rd32(); y1 = (int)rd32(); }
-        else if (name == "lineOrder") line_order = f[vpos];
+        } else if (name == "compression" && n >= 1) compression = f[vpos];
+        else if (name == "dataWindow" && n >= 16) { pos = vpos; x0 = (int)rd32(); y0 = (int)rd32(); x1 = (int)rd32(); y1 = (int)rd32(); }
+        else if (name == "lineOrder" && n >= 1) line_order = f[vpos];
         pos = vpos + n;
     }
     (void)line_order;   // blocks carry their own y coordinate
-    const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-    if (w <= 0 || h <= 0 || chans.empty()) throw std::runtime_error("Failure when loading image: bad OpenEXR header: " + filename);
+    const long long wl = (long long)x1 - x0 + 1, hl = (long long)y1 - y0 + 1;
+    if (wl <= 0 || hl <= 0 || wl > 65536 || hl > 65536 || wl * hl > (1LL << 28) || chans.empty() || chans.size() > 64)
+        throw std::runtime_error("Failure when loading image: bad OpenEXR header: " + filename);
+    const int w = (int)wl, h = (int)hl;
     int lines_per_block;
     if (compression == 0 || compression == 1 || compression == 2) lines_per_block = 1;
     else if (compression == 3) lines_per_block = 16;
@@ -232,9 +237,10 @@ void read_exr_rgb(const std::string &filename, int *width, int *height, std::vec
     rgb->assign((size_t)w * h * 3, 0.f);
     for (int blk = 0; blk < nblocks; blk++) {
         pos = (size_t)offs[(size_t)blk];
-        int by = (int)rd32() - y0;
+        const long long byl = (long long)(int)rd32() - y0;
         uint32_t len = rd32();
         need(len);
+        const int by = (byl < 0 || byl >= h) ? -1 : (int)byl;
         if (by < 0 || by >= h) throw std::runtime_error("Failure when loading image: bad OpenEXR block: " + filename);
         const int lines = std::min(lines_per_block, h - by);
         std::vector<unsigned char> raw((size_t)lines * w * bytes_per_px);

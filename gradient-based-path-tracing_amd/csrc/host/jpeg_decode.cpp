@@ -107,15 +107,18 @@ struct BitReader {
     }
 };
 
-inline uint8_t clamp8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+inline uint8_t clamp8(long long x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
 
 // 12-bit constants exactly as (int)(c * 4096 + 0.5) evaluates in stb (c is a float literal there)
 inline int fx(float c) { return (int)(c * 4096 + 0.5); }
 
-struct Idct1D { int x0, x1, x2, x3, t0, t1, t2, t3; };
-inline Idct1D idct_1d(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7) {
+// 64-bit intermediates: identical to stb's 32-bit arithmetic for every valid stream (whose values stay far inside 32
+// bits) and free of signed overflow on corrupt ones.
+typedef long long I64;
+struct Idct1D { I64 x0, x1, x2, x3, t0, t1, t2, t3; };
+inline Idct1D idct_1d(I64 s0, I64 s1, I64 s2, I64 s3, I64 s4, I64 s5, I64 s6, I64 s7) {
     Idct1D r;
-    int p1, p2, p3, p4, p5, t0, t1, t2, t3;
+    I64 p1, p2, p3, p4, p5, t0, t1, t2, t3;
     p2 = s2; p3 = s6;
     p1 = (p2 + p3) * fx(0.5411961f);
     t2 = p1 + p3 * fx(-1.847759065f);
@@ -140,12 +143,12 @@ inline Idct1D idct_1d(int s0, int s1, int s2, int s3, int s4, int s5, int s6, in
 }
 
 void idct_block(uint8_t *out, int stride, const int16_t d[64]) {
-    int val[64];
+    I64 val[64];
     for (int i = 0; i < 8; i++) {                       // columns
         const int16_t *c = d + i;
-        int *v = val + i;
+        I64 *v = val + i;
         if (c[8] == 0 && c[16] == 0 && c[24] == 0 && c[32] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0) {
-            int dc = c[0] * 4;
+            I64 dc = c[0] * 4;
             v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dc;
         } else {
             Idct1D r = idct_1d(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56]);
@@ -157,10 +160,10 @@ void idct_block(uint8_t *out, int stride, const int16_t d[64]) {
         }
     }
     for (int i = 0; i < 8; i++) {                       // rows
-        const int *v = val + 8 * i;
+        const I64 *v = val + 8 * i;
         uint8_t *o = out + (size_t)i * stride;
         Idct1D r = idct_1d(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-        const int bias = 65536 + (128 << 17);
+        const I64 bias = 65536 + (128 << 17);
         r.x0 += bias; r.x1 += bias; r.x2 += bias; r.x3 += bias;
         o[0] = clamp8((r.x0 + r.t3) >> 17); o[7] = clamp8((r.x0 - r.t3) >> 17);
         o[1] = clamp8((r.x1 + r.t2) >> 17); o[6] = clamp8((r.x1 - r.t2) >> 17);
