@@ -92,8 +92,6 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     if (cam.width <= 0 || cam.height <= 0) throw std::runtime_error("gdpt_scene_upload: empty film");
     for (int m = 0; m < desc->num_materials; m++) {
         int t = desc->materials[m].type;
-        if (t == GDPT_MAT_ROUGHPLASTIC || t == GDPT_MAT_ROUGHDIELECTRIC)
-            throw std::runtime_error("gdpt_scene_upload: RoughPlastic/RoughDielectric are outside the GradPath hot-path subset (SURVEY.md §8(f) rank 4)");
         if (t < 0 || t > GDPT_MAT_DISNEY_BSDF) throw std::runtime_error("gdpt_scene_upload: unknown material type");
         for (int k = 0; k < GDPT_MAT_MAX_TEX; k++) {
             const GdptTexture &tx = desc->materials[m].tex[k];
@@ -310,7 +308,7 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     for (auto &m : materials) for (auto &t : m.tex) if (t.type != GDPT_TEX_CONSTANT) v.all_textures_constant = 0;
     for (auto &m : materials) {
         if (m.type != GDPT_MAT_LAMBERTIAN) sc->lambert_only = false;
-        if (m.type == GDPT_MAT_DISNEY_GLASS || m.type == GDPT_MAT_DISNEY_BSDF) sc->one_sided = false;   // two-sided lobes
+        if (m.type == GDPT_MAT_DISNEY_GLASS || m.type == GDPT_MAT_DISNEY_BSDF || m.type == GDPT_MAT_ROUGHDIELECTRIC) sc->one_sided = false;   // two-sided lobes
     }
     // get_intersection_epsilon (src/scene.h:100-102) from Embree-style fp32 scene bounds (src/scene.cpp:29-33)
     double dx = (double)ub[0] - (double)lb[0], dy = (double)ub[1] - (double)lb[1], dz = (double)ub[2] - (double)lb[2];

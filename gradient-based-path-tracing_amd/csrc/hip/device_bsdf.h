@@ -370,12 +370,130 @@ GD bool db_sample(const Ctx &c, const GdptMaterial &m, D3 in, D2 ruv, double rw,
     return dg_sample(c, m.tex[5], p.eta, in, ruv, rw, s);
 }
 
+// ---- RoughPlastic / RoughDielectric: src/materials/roughplastic.inl, roughdielectric.inl ----
+GD double gtr2_iso(double n_dot_h, double roughness) {               // GTR2, src/microfacet.h:58-63
+    double alpha = roughness * roughness;
+    double a2 = alpha * alpha;
+    double t = 1 + (a2 - 1) * n_dot_h * n_dot_h;
+    return a2 / (kPi * t * t);
+}
+GD double smith_gtr2_iso(D3 v_local, double roughness) {             // smith_masking_gtr2, src/microfacet.h:72-78
+    double alpha = roughness * roughness;
+    double a2 = alpha * alpha;
+    D3 v2 = v_local * v_local;
+    double Lambda = (-1 + sqrt(1 + (v2.x * a2 + v2.y * a2) / v2.z)) / 2;
+    return 1 / (1 + Lambda);
+}
+GD double clamp_rough(double r) { return fmin(fmax(r, 0.01), 1.0); }
+GD D3 rp_eval(const Ctx &c, const GdptMaterial &m, D3 in, D3 out) {                      // roughplastic.inl:3-43
+    if (dot(c.v.gn, in) < 0 || dot(c.v.gn, out) < 0) return splat(0);
+    Frame f = oriented_frame(c.v, in);
+    D3 h = normalize(in + out);
+    double n_dot_h = dot(f.n, h), n_dot_in = dot(f.n, in), n_dot_out = dot(f.n, out);
+    if (n_dot_out <= 0 || n_dot_h <= 0) return splat(0);
+    D3 Kd = T3(c, m.tex[0]), Ks = T3(c, m.tex[1]);
+    double roughness = clamp_rough(T1(c, m.tex[2]));
+    double F_o = fresnel_dielectric(dot(h, out), m.eta);
+    double D = gtr2_iso(n_dot_h, roughness);
+    double G = smith_gtr2_iso(to_local(f, in), roughness) * smith_gtr2_iso(to_local(f, out), roughness);
+    D3 spec = Ks * (G * F_o * D) / (4 * n_dot_in * n_dot_out);
+    double F_i = fresnel_dielectric(dot(h, in), m.eta);
+    D3 diff = Kd * (1.0 - F_o) * (1.0 - F_i) / kPi;
+    return (spec + diff) * n_dot_out;
+}
+GD double rp_pdf(const Ctx &c, const GdptMaterial &m, D3 in, D3 out) {                   // roughplastic.inl:45-88
+    if (dot(c.v.gn, in) < 0 || dot(c.v.gn, out) < 0) return 0;
+    Frame f = oriented_frame(c.v, in);
+    D3 h = normalize(in + out);
+    double n_dot_in = dot(f.n, in), n_dot_out = dot(f.n, out), n_dot_h = dot(f.n, h);
+    if (n_dot_out <= 0 || n_dot_h <= 0) return 0;
+    double lS = luminance(T3(c, m.tex[1])), lR = luminance(T3(c, m.tex[0]));
+    if (lS + lR <= 0) return 0;
+    double roughness = clamp_rough(T1(c, m.tex[2]));
+    double spec_prob = lS / (lS + lR);
+    double diff_prob = 1 - spec_prob;
+    double G = smith_gtr2_iso(to_local(f, in), roughness);
+    double D = gtr2_iso(n_dot_h, roughness);
+    spec_prob *= (G * D) / (4 * n_dot_in);
+    diff_prob *= n_dot_out / kPi;
+    return spec_prob + diff_prob;
+}
+GD bool rp_sample(const Ctx &c, const GdptMaterial &m, D3 in, D2 ruv, double rw, BsdfSample &s) {   // :90-137
+    if (dot(c.v.gn, in) < 0) return false;
+    Frame f = oriented_frame(c.v, in);
+    double lS = luminance(T3(c, m.tex[1])), lR = luminance(T3(c, m.tex[0]));
+    if (lS + lR <= 0) return false;
+    double spec_prob = lS / (lS + lR);
+    if (rw < spec_prob) {
+        double roughness = clamp_rough(T1(c, m.tex[2]));
+        double alpha = roughness * roughness;
+        D3 h = to_world(f, sample_visible_normals(to_local(f, in), alpha, alpha, ruv));
+        s.dir_out = normalize(-in + 2 * dot(in, h) * h); s.eta = 0; s.roughness = roughness;
+    } else {
+        s.dir_out = to_world(f, sample_cos_hemisphere(ruv)); s.eta = 0; s.roughness = 1;
+    }
+    return true;
+}
+struct RdTerms { bool reflect; Frame f; double eta, roughness, h_dot_in, F, D; D3 h; };
+GD RdTerms rd_terms(const Ctx &c, const GdptMaterial &m, D3 in, D3 out) {                // roughdielectric.inl:4-37,52-78
+    RdTerms t;
+    t.reflect = dot(c.v.gn, in) * dot(c.v.gn, out) > 0;
+    t.f = oriented_frame_2s(c.v, in);
+    t.eta = dot(c.v.gn, in) > 0 ? m.eta : 1 / m.eta;
+    t.h = t.reflect ? normalize(in + out) : normalize(in + out * t.eta);
+    if (dot(t.h, t.f.n) < 0) t.h = -t.h;
+    t.roughness = clamp_rough(T1(c, m.tex[2]));
+    t.h_dot_in = dot(t.h, in);
+    t.F = fresnel_dielectric(t.h_dot_in, t.eta);
+    t.D = gtr2_iso(dot(t.f.n, t.h), t.roughness);
+    return t;
+}
+GD D3 rd_eval(const Ctx &c, const GdptMaterial &m, D3 in, D3 out) {                      // roughdielectric.inl:3-49
+    RdTerms t = rd_terms(c, m, in, out);
+    D3 Ks = T3(c, m.tex[0]), Kt = T3(c, m.tex[1]);
+    double G = smith_gtr2_iso(to_local(t.f, in), t.roughness) * smith_gtr2_iso(to_local(t.f, out), t.roughness);
+    if (t.reflect) return Ks * (t.F * t.D * G) / (4 * fabs(dot(t.f.n, in)));
+    double eta_factor = 1 / (t.eta * t.eta);                  // TransportDirection::TO_LIGHT, the default of eval()
+    double h_dot_out = dot(t.h, out);
+    double sd = t.h_dot_in + t.eta * h_dot_out;
+    return Kt * (eta_factor * (1 - t.F) * t.D * G * t.eta * t.eta * fabs(h_dot_out * t.h_dot_in)) / (fabs(dot(t.f.n, in)) * sd * sd);
+}
+GD double rd_pdf(const Ctx &c, const GdptMaterial &m, D3 in, D3 out) {                   // roughdielectric.inl:51-93
+    RdTerms t = rd_terms(c, m, in, out);
+    double G_in = smith_gtr2_iso(to_local(t.f, in), t.roughness);
+    if (t.reflect) return (t.F * t.D * G_in) / (4 * fabs(dot(t.f.n, in)));
+    double h_dot_out = dot(t.h, out);
+    double sd = t.h_dot_in + t.eta * h_dot_out;
+    double dh_dout = t.eta * t.eta * h_dot_out / (sd * sd);
+    return (1 - t.F) * t.D * G_in * fabs(dh_dout * t.h_dot_in / dot(t.f.n, in));
+}
+GD bool rd_sample(const Ctx &c, const GdptMaterial &m, D3 in, D2 ruv, double rw, BsdfSample &s) {   // :95-139
+    double eta = dot(c.v.gn, in) > 0 ? m.eta : 1 / m.eta;
+    Frame f = oriented_frame_2s(c.v, in);
+    double roughness = clamp_rough(T1(c, m.tex[2]));
+    double alpha = roughness * roughness;
+    D3 h = to_world(f, sample_visible_normals(to_local(f, in), alpha, alpha, ruv));
+    if (dot(h, f.n) < 0) h = -h;
+    double h_dot_in = dot(h, in);
+    double F = fresnel_dielectric(h_dot_in, eta);
+    if (rw <= F) {
+        s.dir_out = normalize(-in + 2 * dot(in, h) * h); s.eta = 0; s.roughness = roughness;
+        return true;
+    }
+    double h_dot_out_sq = 1 - (1 - h_dot_in * h_dot_in) / (eta * eta);
+    if (h_dot_out_sq <= 0) return false;
+    if (h_dot_in < 0) h = -h;
+    double h_dot_out = sqrt(h_dot_out_sq);
+    s.dir_out = -in / eta + (fabs(h_dot_in) / eta - h_dot_out) * h; s.eta = eta; s.roughness = roughness;
+    return true;
+}
+
 // ---- dispatch (std::visit in the reference, src/material.cpp:90-119) -------------------------------
-// Returns false for material types outside the restated subset (RoughPlastic, RoughDielectric):
-// gdpt_scene_upload refuses such scenes, so the kernels never see them.
 GD D3 bsdf_eval(const DevSceneView &sv, const GdptMaterial &m, D3 in, D3 out, const Vertex &v) {
     Ctx c{sv, v};
     switch (m.type) {
+        case GDPT_MAT_ROUGHPLASTIC: return rp_eval(c, m, in, out);
+        case GDPT_MAT_ROUGHDIELECTRIC: return rd_eval(c, m, in, out);
         case GDPT_MAT_LAMBERTIAN: return lambert_eval(c, m.tex[0], in, out);
         case GDPT_MAT_DISNEY_DIFFUSE: return dd_eval(c, m.tex[0], m.tex[1], m.tex[2], in, out);
         case GDPT_MAT_DISNEY_METAL: return dm_eval(c, T3(c, m.tex[0]), m.tex[1], m.tex[2], in, out);
@@ -389,6 +507,8 @@ GD D3 bsdf_eval(const DevSceneView &sv, const GdptMaterial &m, D3 in, D3 out, co
 GD double bsdf_pdf(const DevSceneView &sv, const GdptMaterial &m, D3 in, D3 out, const Vertex &v) {
     Ctx c{sv, v};
     switch (m.type) {
+        case GDPT_MAT_ROUGHPLASTIC: return rp_pdf(c, m, in, out);
+        case GDPT_MAT_ROUGHDIELECTRIC: return rd_pdf(c, m, in, out);
         case GDPT_MAT_LAMBERTIAN: case GDPT_MAT_DISNEY_DIFFUSE: case GDPT_MAT_DISNEY_SHEEN: return cos_pdf(c, in, out);
         case GDPT_MAT_DISNEY_METAL: return dm_pdf(c, m.tex[1], m.tex[2], in, out);
         case GDPT_MAT_DISNEY_GLASS: return dg_pdf(c, m.tex[1], m.tex[2], m.eta, in, out);
@@ -400,6 +520,8 @@ GD double bsdf_pdf(const DevSceneView &sv, const GdptMaterial &m, D3 in, D3 out,
 GD bool bsdf_sample(const DevSceneView &sv, const GdptMaterial &m, D3 in, const Vertex &v, D2 ruv, double rw, BsdfSample &s) {
     Ctx c{sv, v};
     switch (m.type) {
+        case GDPT_MAT_ROUGHPLASTIC: return rp_sample(c, m, in, ruv, rw, s);
+        case GDPT_MAT_ROUGHDIELECTRIC: return rd_sample(c, m, in, ruv, rw, s);
         case GDPT_MAT_LAMBERTIAN: case GDPT_MAT_DISNEY_SHEEN: return cos_sample(c, in, ruv, 1.0, s);
         case GDPT_MAT_DISNEY_DIFFUSE: return dd_sample(c, m.tex[1], in, ruv, s);
         case GDPT_MAT_DISNEY_METAL: return dm_sample(c, m.tex[1], m.tex[2], in, ruv, s);

@@ -792,9 +792,129 @@ bool db_sample(const Ctx &c, const GdptMaterial &m, const V3 &in, const V2 &ruv,
     std::fprintf(stderr, "oracle: material type %d is outside the restated subset\n", type);
     std::abort();
 }
+// ---- RoughPlastic / RoughDielectric: src/materials/roughplastic.inl, roughdielectric.inl ----
+inline Real gtr2_iso(Real n_dot_h, Real roughness) {                 // GTR2, src/microfacet.h:58-63
+    Real alpha = roughness * roughness;
+    Real a2 = alpha * alpha;
+    Real t = 1 + (a2 - 1) * n_dot_h * n_dot_h;
+    return a2 / (c_PI * t * t);
+}
+inline Real smith_gtr2_iso(const V3 &v_local, Real roughness) {      // smith_masking_gtr2, src/microfacet.h:72-78
+    Real alpha = roughness * roughness;
+    Real a2 = alpha * alpha;
+    V3 v2 = v_local * v_local;
+    Real Lambda = (-1 + std::sqrt(1 + (v2.x * a2 + v2.y * a2) / v2.z)) / 2;
+    return 1 / (1 + Lambda);
+}
+V3 rp_eval(const Ctx &c, const GdptMaterial &m, const V3 &in, const V3 &out) {           // roughplastic.inl:3-43
+    if (dot(c.v.geometric_normal, in) < 0 || dot(c.v.geometric_normal, out) < 0) return {0, 0, 0};
+    Frame f = oriented_frame(c.v, in);
+    V3 h = normalize(in + out);
+    Real n_dot_h = dot(f.n, h), n_dot_in = dot(f.n, in), n_dot_out = dot(f.n, out);
+    if (n_dot_out <= 0 || n_dot_h <= 0) return {0, 0, 0};
+    V3 Kd = T3(c, m.tex[0]), Ks = T3(c, m.tex[1]);
+    Real roughness = std::clamp(T1(c, m.tex[2]), Real(0.01), Real(1));
+    Real F_o = fresnel_dielectric(dot(h, out), m.eta);
+    Real D = gtr2_iso(n_dot_h, roughness);
+    Real G = smith_gtr2_iso(to_local(f, in), roughness) * smith_gtr2_iso(to_local(f, out), roughness);
+    V3 spec = Ks * (G * F_o * D) / (4 * n_dot_in * n_dot_out);
+    Real F_i = fresnel_dielectric(dot(h, in), m.eta);
+    V3 diff = Kd * (Real(1) - F_o) * (Real(1) - F_i) / c_PI;
+    return (spec + diff) * n_dot_out;
+}
+Real rp_pdf(const Ctx &c, const GdptMaterial &m, const V3 &in, const V3 &out) {          // roughplastic.inl:45-88
+    if (dot(c.v.geometric_normal, in) < 0 || dot(c.v.geometric_normal, out) < 0) return 0;
+    Frame f = oriented_frame(c.v, in);
+    V3 h = normalize(in + out);
+    Real n_dot_in = dot(f.n, in), n_dot_out = dot(f.n, out), n_dot_h = dot(f.n, h);
+    if (n_dot_out <= 0 || n_dot_h <= 0) return 0;
+    Real lS = luminance(T3(c, m.tex[1])), lR = luminance(T3(c, m.tex[0]));
+    if (lS + lR <= 0) return 0;
+    Real roughness = std::clamp(T1(c, m.tex[2]), Real(0.01), Real(1));
+    Real spec_prob = lS / (lS + lR);
+    Real diff_prob = 1 - spec_prob;
+    Real G = smith_gtr2_iso(to_local(f, in), roughness);
+    Real D = gtr2_iso(n_dot_h, roughness);
+    spec_prob *= (G * D) / (4 * n_dot_in);
+    diff_prob *= n_dot_out / c_PI;
+    return spec_prob + diff_prob;
+}
+bool rp_sample(const Ctx &c, const GdptMaterial &m, const V3 &in, const V2 &ruv, Real rw, BsdfSample *s) {   // :90-137
+    if (dot(c.v.geometric_normal, in) < 0) return false;
+    Frame f = oriented_frame(c.v, in);
+    Real lS = luminance(T3(c, m.tex[1])), lR = luminance(T3(c, m.tex[0]));
+    if (lS + lR <= 0) return false;
+    Real spec_prob = lS / (lS + lR);
+    if (rw < spec_prob) {
+        V3 li = to_local(f, in);
+        Real roughness = std::clamp(T1(c, m.tex[2]), Real(0.01), Real(1));
+        Real alpha = roughness * roughness;
+        V3 h = to_world(f, sample_visible_normals(li, alpha, alpha, ruv));
+        s->dir_out = normalize(-in + 2 * dot(in, h) * h); s->eta = 0; s->roughness = roughness;
+    } else {
+        s->dir_out = to_world(f, sample_cos_hemisphere(ruv)); s->eta = 0; s->roughness = 1;
+    }
+    return true;
+}
+struct RdTerms { bool reflect; Frame f; Real eta, roughness, h_dot_in, F, D; V3 h; };
+RdTerms rd_terms(const Ctx &c, const GdptMaterial &m, const V3 &in, const V3 &out) {     // roughdielectric.inl:4-37,52-78
+    RdTerms t;
+    t.reflect = dot(c.v.geometric_normal, in) * dot(c.v.geometric_normal, out) > 0;
+    t.f = oriented_frame_2s(c.v, in);
+    t.eta = dot(c.v.geometric_normal, in) > 0 ? m.eta : 1 / m.eta;
+    t.h = t.reflect ? normalize(in + out) : normalize(in + out * t.eta);
+    if (dot(t.h, t.f.n) < 0) t.h = -t.h;
+    t.roughness = std::clamp(T1(c, m.tex[2]), Real(0.01), Real(1));
+    t.h_dot_in = dot(t.h, in);
+    t.F = fresnel_dielectric(t.h_dot_in, t.eta);
+    t.D = gtr2_iso(dot(t.f.n, t.h), t.roughness);
+    return t;
+}
+V3 rd_eval(const Ctx &c, const GdptMaterial &m, const V3 &in, const V3 &out) {           // roughdielectric.inl:3-49
+    RdTerms t = rd_terms(c, m, in, out);
+    V3 Ks = T3(c, m.tex[0]), Kt = T3(c, m.tex[1]);
+    Real G = smith_gtr2_iso(to_local(t.f, in), t.roughness) * smith_gtr2_iso(to_local(t.f, out), t.roughness);
+    if (t.reflect) return Ks * (t.F * t.D * G) / (4 * std::fabs(dot(t.f.n, in)));
+    Real eta_factor = 1 / (t.eta * t.eta);                    // TransportDirection::TO_LIGHT, the default of eval() (src/material.h)
+    Real h_dot_out = dot(t.h, out);
+    Real sd = t.h_dot_in + t.eta * h_dot_out;
+    return Kt * (eta_factor * (1 - t.F) * t.D * G * t.eta * t.eta * std::fabs(h_dot_out * t.h_dot_in)) / (std::fabs(dot(t.f.n, in)) * sd * sd);
+}
+Real rd_pdf(const Ctx &c, const GdptMaterial &m, const V3 &in, const V3 &out) {          // roughdielectric.inl:51-93
+    RdTerms t = rd_terms(c, m, in, out);
+    Real G_in = smith_gtr2_iso(to_local(t.f, in), t.roughness);
+    if (t.reflect) return (t.F * t.D * G_in) / (4 * std::fabs(dot(t.f.n, in)));
+    Real h_dot_out = dot(t.h, out);
+    Real sd = t.h_dot_in + t.eta * h_dot_out;
+    Real dh_dout = t.eta * t.eta * h_dot_out / (sd * sd);
+    return (1 - t.F) * t.D * G_in * std::fabs(dh_dout * t.h_dot_in / dot(t.f.n, in));
+}
+bool rd_sample(const Ctx &c, const GdptMaterial &m, const V3 &in, const V2 &ruv, Real rw, BsdfSample *s) {   // :95-139
+    Real eta = dot(c.v.geometric_normal, in) > 0 ? m.eta : 1 / m.eta;
+    Frame f = oriented_frame_2s(c.v, in);
+    Real roughness = std::clamp(T1(c, m.tex[2]), Real(0.01), Real(1));
+    Real alpha = roughness * roughness;
+    V3 h = to_world(f, sample_visible_normals(to_local(f, in), alpha, alpha, ruv));
+    if (dot(h, f.n) < 0) h = -h;
+    Real h_dot_in = dot(h, in);
+    Real F = fresnel_dielectric(h_dot_in, eta);
+    if (rw <= F) {
+        s->dir_out = normalize(-in + 2 * dot(in, h) * h); s->eta = 0; s->roughness = roughness;
+        return true;
+    }
+    Real h_dot_out_sq = 1 - (1 - h_dot_in * h_dot_in) / (eta * eta);
+    if (h_dot_out_sq <= 0) return false;
+    if (h_dot_in < 0) h = -h;
+    Real h_dot_out = std::sqrt(h_dot_out_sq);
+    s->dir_out = -in / eta + (std::fabs(h_dot_in) / eta - h_dot_out) * h; s->eta = eta; s->roughness = roughness;
+    return true;
+}
+
 V3 bsdf_eval(const OracleScene &sc, const GdptMaterial &m, const V3 &in, const V3 &out, const Vertex &v) {
     Ctx c{sc, v};
     switch (m.type) {
+        case GDPT_MAT_ROUGHPLASTIC: return rp_eval(c, m, in, out);
+        case GDPT_MAT_ROUGHDIELECTRIC: return rd_eval(c, m, in, out);
         case GDPT_MAT_LAMBERTIAN: return lambert_eval(c, m.tex[0], in, out);
         case GDPT_MAT_DISNEY_DIFFUSE: return dd_eval(c, m.tex[0], m.tex[1], m.tex[2], in, out);
         case GDPT_MAT_DISNEY_METAL: return dm_eval(c, T3(c, m.tex[0]), m.tex[1], m.tex[2], in, out);
@@ -808,6 +928,8 @@ V3 bsdf_eval(const OracleScene &sc, const GdptMaterial &m, const V3 &in, const V
 Real bsdf_pdf(const OracleScene &sc, const GdptMaterial &m, const V3 &in, const V3 &out, const Vertex &v) {
     Ctx c{sc, v};
     switch (m.type) {
+        case GDPT_MAT_ROUGHPLASTIC: return rp_pdf(c, m, in, out);
+        case GDPT_MAT_ROUGHDIELECTRIC: return rd_pdf(c, m, in, out);
         case GDPT_MAT_LAMBERTIAN: case GDPT_MAT_DISNEY_DIFFUSE: case GDPT_MAT_DISNEY_SHEEN: return cos_pdf(c, in, out);
         case GDPT_MAT_DISNEY_METAL: return dm_pdf(c, m.tex[1], m.tex[2], in, out);
         case GDPT_MAT_DISNEY_GLASS: return dg_pdf(c, m.tex[1], m.tex[2], m.eta, in, out);
@@ -819,6 +941,8 @@ Real bsdf_pdf(const OracleScene &sc, const GdptMaterial &m, const V3 &in, const 
 bool bsdf_sample(const OracleScene &sc, const GdptMaterial &m, const V3 &in, const Vertex &v, const V2 &ruv, Real rw, BsdfSample *s) {
     Ctx c{sc, v};
     switch (m.type) {
+        case GDPT_MAT_ROUGHPLASTIC: return rp_sample(c, m, in, ruv, rw, s);
+        case GDPT_MAT_ROUGHDIELECTRIC: return rd_sample(c, m, in, ruv, rw, s);
         case GDPT_MAT_LAMBERTIAN: case GDPT_MAT_DISNEY_SHEEN: return cos_sample(c, in, ruv, Real(1), s);
         case GDPT_MAT_DISNEY_DIFFUSE: return dd_sample(c, m.tex[1], in, ruv, s);
         case GDPT_MAT_DISNEY_METAL: return dm_sample(c, m.tex[1], m.tex[2], in, ruv, s);

@@ -141,6 +141,10 @@ static void emit_bsdfs() {
     mats.push_back({"disneysheen", DisneySheen{cs(0.82, 0.67, 0.16), cf(0.4)}});
     mats.push_back({"disneybsdf", DisneyBSDF{cs(0.82, 0.67, 0.16), cf(0.5), cf(0.5), cf(0.5), cf(0.5), cf(0.1), cf(0.5), cf(0.5), cf(0.5), cf(0.5), cf(0.5), cf(0.5), 1.5}});
     mats.push_back({"disneybsdf_b", DisneyBSDF{cs(0.2, 0.5, 0.9), cf(0.1), cf(0.2), cf(0.3), cf(0.8), cf(0.45), cf(0.25), cf(0.0), cf(1.0), cf(0.3), cf(0.9), cf(0.2), 1.33}});
+    mats.push_back({"roughplastic", RoughPlastic{cs(0.6, 0.3, 0.2), cs(0.9, 0.9, 0.8), cf(0.25), 1.49 / 1.000277}});
+    mats.push_back({"roughplastic_checker", RoughPlastic{checker, cs(1.0, 1.0, 1.0), cf(0.004), 1.3}});
+    mats.push_back({"roughdielectric", RoughDielectric{cs(0.95, 0.9, 1.0), cs(0.8, 0.9, 0.7), cf(0.3), 1.5046 / 1.000277}});
+    mats.push_back({"roughdielectric_smooth", RoughDielectric{cs(1.0, 1.0, 1.0), cs(1.0, 1.0, 1.0), cf(0.02), 1.33}});
     mats.push_back({"disneybsdf_black", DisneyBSDF{cs(0.0, 0.0, 0.0), cf(0.9), cf(0.0), cf(0.0), cf(0.5), cf(0.7), cf(1.0), cf(0.9), cf(0.0), cf(0.5), cf(0.0), cf(1.0), 1.8}});
     printf("\"bsdf\":[");
     bool first = true;

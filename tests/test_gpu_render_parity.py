@@ -220,9 +220,28 @@ def test_argument_errors(G, scene_tmp):
         sc.render(4, G.RNG_TILE, rows=(8, 32))          # tile-stream bands must be whole tile rows
     with pytest.raises(G.GdptError):
         sc.render(4, 99)
-    rp = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=16, height=16)
-    text = open(rp).read().replace('<bsdf type="diffuse" id="box">', '<bsdf type="roughplastic" id="box">')
-    open(rp, "w").write(text)
-    with pytest.raises(G.GdptError) as e:
-        G.Scene(G.parse_scene(rp))
-    assert "RoughPlastic" in str(e.value)
+
+
+def test_roughplastic_and_roughdielectric_boxes(G, O, scene_tmp):
+    """the cbox with its two boxes switched to RoughPlastic (one-sided: lane machine with lazy
+    offsets) and RoughDielectric (two-sided: eager evaluator), GradPath and Path against the oracle."""
+    for variant, tol in ((("roughplastic",), 1e-9), (("roughplastic", "roughdielectric"), 1e-7)):
+        xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=40, height=32)
+        text = open(xml).read()
+        text = text.replace('<bsdf type="diffuse" id="box">', '<bsdf type="roughplastic" id="box"><float name="alpha" value="0.1"/>', 1)
+        if len(variant) > 1:
+            # the first shape that references "box" becomes a rough glass block with its own material
+            text = text.replace('</bsdf>', '</bsdf>\n<bsdf type="roughdielectric" id="glassbox"><float name="alpha" value="0.05"/><float name="intIOR" value="1.4"/></bsdf>', 1)
+            text = text.replace('<ref id="box"/>', '<ref id="glassbox"/>', 1)
+        open(xml, "w").write(text)
+        sd = G.parse_scene(xml)
+        types = sorted({sd.desc.materials[i].type for i in range(sd.desc.num_materials)})
+        assert G.MAT_ROUGHPLASTIC in types and ((G.MAT_ROUGHDIELECTRIC in types) == (len(variant) > 1))
+        sc = G.Scene(sd)
+        got, st = sc.render(6, G.RNG_SAMPLE)
+        want, ost = O.OracleScene(sd.ptr).render(6, G.RNG_SAMPLE, threads=8)
+        assert st.bounces == ost.bounces
+        check_buffers(got, want, tol)
+        img, pst = sc.path_render(4, G.RNG_SAMPLE)
+        pwant, post = O.OracleScene(sd.ptr).path_render(4, G.RNG_SAMPLE, threads=8)
+        assert rel_l2(img, pwant) < tol and pst.bounces == post.bounces
