@@ -411,8 +411,23 @@ void path_render_device_impl(GdptScene *sc, const GdptRenderParams *params, doub
     rl.img = img;
     rl.counters = sc->d_counters;
     rl.count_traversal = stats && stats->nodes_visited == ~0ull;
-    const char *k = std::getenv("GDPT_LOG2K");
-    rl.force_log2k = k ? std::atoi(k) : -1;
+    auto env_int = [](const char *name, int def) { const char *v = std::getenv(name); return v ? std::atoi(v) : def; };
+    rl.force_log2k = env_int("GDPT_LOG2K", -1);
+    rl.force_eager = env_int("GDPT_FORCE_EAGER", 0) != 0;
+    rl.thresh_a = env_int("GDPT_KEEP_FRAC", -1); rl.thresh_c = env_int("GDPT_SEARCH_FRAC", -1);
+    rl.num_cus = sc->num_cus; rl.blocks_per_cu = env_int("GDPT_BLOCKS_PER_CU", 0);
+    rl.lambert_only = sc->lambert_only;
+    rl.scene_fits_lds = !env_int("GDPT_NO_LDS_SCENE", 0) &&
+                        gdpt::scene_fits_lds_wide(sc->view.num_nodes4, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->wide_stack_need);
+    {
+        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, b.spp, rl.force_log2k);
+        if (need > sc->partials_doubles) {
+            if (sc->d_partials) { ck(hipStreamSynchronize(stream), "hipStreamSynchronize"); hipFree(sc->d_partials); sc->d_partials = nullptr; }
+            ck(hipMalloc((void **)&sc->d_partials, need * sizeof(double)), "hipMalloc(work-item partials)");
+            sc->partials_doubles = need;
+        }
+        rl.partials = sc->d_partials; rl.queue_head = sc->d_queue;
+    }
     ck(hipMemsetAsync(sc->d_counters, 0, sizeof(gdpt::RenderCounters), stream), "hipMemsetAsync(counters)");
     if (stats) ck(hipEventRecord(sc->ev0, stream), "hipEventRecord");
     gdpt::launch_path_render(sc->view, rl, stream);

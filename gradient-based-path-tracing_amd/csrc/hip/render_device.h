@@ -653,6 +653,40 @@ GD bool item_to_pixel(const KernelArgs &a, int W, unsigned item, int &x, int &y,
     return x < W && y < a.row_end;
 }
 
+// A wave's view of the global work queue. Every lane of the wave calls take(); idle lanes may receive an item index.
+// Slices are fetched with one atomicAdd per refill: 64 items while plenty are left; towards the end only what the idle
+// lanes (and a fair share of the remainder) can start now, so that no wave sits on unstarted items while others have
+// run dry.
+struct WaveQueue {
+    long long next = 0, end = 0, seen_head = 0;
+    bool exhausted = false;
+    GD long long take(const KernelArgs &a, bool idle, int tid) {
+        long long item = -1;
+        const unsigned long long m_idle = __ballot(idle);
+        if (m_idle) {
+            if (next >= end && !exhausted) {
+                const long long left = a.num_items - seen_head;
+                long long want = left / ((long long)gridDim.x * (kBlock / 64) * 4);
+                const long long n_idle_now = __popcll(m_idle);
+                want = want > 64 ? 64 : (want < n_idle_now ? n_idle_now : want);
+                unsigned long long got = 0;
+                if ((tid & 63) == 0) got = atomicAdd(a.queue_head, (unsigned long long)want);
+                got = __shfl(got, 0, 64);
+                next = (long long)got;
+                end = min((long long)got + want, a.num_items);
+                seen_head = end;
+                if (next >= a.num_items) { exhausted = true; end = next; }
+            }
+            const int avail = (int)(end - next);
+            const int rank = __popcll(m_idle & ((1ull << (tid & 63)) - 1ull));
+            if (idle && rank < avail) item = next + rank;
+            const int n_idle = __popcll(m_idle);
+            next += (n_idle < avail) ? n_idle : avail;
+        }
+        return item;
+    }
+};
+
 // SAMPLE stream, persistent threads. Every lane repeatedly takes a work item (pixel, chunk of the pixel's samples)
 // from a global queue — fetched 64 at a time per wave with one atomicAdd — and runs the lane machine on it; a lane
 // that finishes early picks up the next item instead of idling behind the longest path of its wave. Per-item sums go
@@ -683,10 +717,7 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
     int x = 0, y = 0;
     unsigned long long base = 0;
     long long my_item = -1;
-    // wave-local slice of the queue (uniform across the wave)
-    long long q_next = 0, q_end = 0, seen_head = 0;
-    bool exhausted = false;
-    const unsigned long long lane_lt = (1ull << (tid & 63)) - 1ull;
+    WaveQueue wq;
     for (;;) {
         // ---- hand out work to idle lanes
         const bool idle = (L.st == S_DONE);
@@ -700,37 +731,16 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
             acc.init();
             my_item = -1;
         }
-        const unsigned long long m_idle = __ballot(idle);
-        if (m_idle) {
-            if (q_next >= q_end && !exhausted) {        // refill the wave's slice with one atomic
-                // 64 items while plenty are left; towards the end only what the idle lanes (and a fair share of the
-                // remainder) can start now, so that no wave sits on unstarted items while others have run dry
-                const long long left = a.num_items - seen_head;
-                long long want = left / ((long long)gridDim.x * (kBlock / 64) * 4);
-                const long long n_idle_now = __popcll(m_idle);
-                want = want > 64 ? 64 : (want < n_idle_now ? n_idle_now : want);
-                unsigned long long got = 0;
-                if ((tid & 63) == 0) got = atomicAdd(a.queue_head, (unsigned long long)want);
-                got = __shfl(got, 0, 64);
-                q_next = (long long)got;
-                q_end = min((long long)got + want, a.num_items);
-                seen_head = q_end;
-                if (q_next >= a.num_items) { exhausted = true; q_end = q_next; }
-            }
-            const int avail = (int)(q_end - q_next);
-            const int rank = __popcll(m_idle & lane_lt);
-            if (idle && rank < avail) {
-                my_item = q_next + rank;
-                int s0, s1;
-                const bool inside = item_to_pixel(a, W, (unsigned)my_item, x, y, s0, s1);
-                base = ((unsigned long long)y * W + x) * (unsigned long long)a.spp;
-                L.s = s0; L.s_end = s1;
-                L.st = (inside && s0 < s1) ? S_START : S_DONE;
-            }
-            const int n_idle = __popcll(m_idle);
-            q_next += (n_idle < avail) ? n_idle : avail;
+        const long long got_item = wq.take(a, idle, tid);
+        if (got_item >= 0) {
+            my_item = got_item;
+            int s0, s1;
+            const bool inside = item_to_pixel(a, W, (unsigned)my_item, x, y, s0, s1);
+            base = ((unsigned long long)y * W + x) * (unsigned long long)a.spp;
+            L.s = s0; L.s_end = s1;
+            L.st = (inside && s0 < s1) ? S_START : S_DONE;
         }
-        if (!__any(L.st != S_DONE)) { if (exhausted) break; else continue; }
+        if (!__any(L.st != S_DONE)) { if (wq.exhausted) break; else continue; }
         trace_pending<TraceCfg<WW, WIDE, !LDS_SCENE>>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
         if (lane_ready(L, tv)) {
             if (tx.count) { tc.lane_steps++; if (wave_leader()) tc.wave_steps++; }
@@ -986,5 +996,6 @@ void launch_tile_phases_general(const DevSceneView &sv, const gd::KernelArgs &a,
 void launch_eager(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, hipStream_t stream);
 void launch_tile_eager(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
 void launch_path(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, hipStream_t stream);
+void launch_path_persistent(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lambert, hipStream_t stream);
 void launch_tile_path(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
 } // namespace gdpt

@@ -80,8 +80,26 @@ void launch_path_render(const DevSceneView &sv, const RenderLaunch &rl, hipStrea
     if (rl.rng_scheme == GDPT_RNG_TILE) {
         int ntx = (W + 15) / 16, nty = (sv.cam.height + 15) / 16;
         launch_tile_path(sv, a, dim3((unsigned)((ntx * nty + 63) / 64)), ntx, nty, stream);
+    } else if (rl.rng_scheme == GDPT_RNG_SAMPLE && !rl.force_eager) {
+        // persistent lanes pulling (pixel, chunk) items, as the GradPath kernel does
+        a.thresh_a = rl.thresh_a >= 0 ? (rl.thresh_a > 255 ? 255 : rl.thresh_a) : 64;
+        a.thresh_c = rl.thresh_c >= 0 ? (rl.thresh_c > 255 ? 255 : rl.thresh_c) : 112;
+        a.log2c = render_log2_chunks(rl.spp, rl.force_log2k);
+        a.tiles_x = (W + 15) / 16;
+        const long long tiles = (long long)a.tiles_x * ((rows + 15) / 16);
+        a.num_items = (tiles * 256) << a.log2c;
+        if (a.num_items >= (1LL << 32)) throw std::runtime_error("launch_path_render: image band too large for the 32-bit work queue");
+        a.partials = rl.partials; a.queue_head = rl.queue_head;
+        if (!a.partials || !a.queue_head) throw std::runtime_error("launch_path_render: work-queue buffers missing");
+        hipError_t me = hipMemsetAsync(a.queue_head, 0, sizeof(unsigned long long), stream);
+        if (me != hipSuccess) throw std::runtime_error("launch_path_render: queue reset failed");
+        long long waves_needed = (a.num_items + 63) / 64;
+        long long blocks = (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2);
+        if (blocks > (waves_needed + 3) / 4) blocks = (waves_needed + 3) / 4;
+        if (blocks < 1) blocks = 1;
+        launch_path_persistent(sv, a, dim3((unsigned)blocks), rl.scene_fits_lds, rl.lambert_only, stream);
     } else if (rl.rng_scheme == GDPT_RNG_SAMPLE) {
-        // static mapping, K = 2^log2k lanes per pixel (enough lanes to fill the chip on small films)
+        // straight per-sample loop (A/B checks): static mapping, K = 2^log2k lanes per pixel
         long long pixels = (long long)W * rows;
         int log2k = 0;
         while ((1 << (log2k + 1)) <= rl.spp && log2k < 6 && (pixels << log2k) < (1LL << 19)) log2k++;

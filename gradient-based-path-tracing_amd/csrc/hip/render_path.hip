@@ -241,11 +241,268 @@ __global__ __launch_bounds__(64) void gdpt_path_tile_stream(DevSceneView sv, Ker
     flush_counters(a, lc, tc, a.count != 0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// persistent lane machine for Integrator::Path (same structure as gdpt_render_phases, render_device.h §"lane machine")
+// ------------------------------------------------------------------------------------------------
+// A lane holds one pending ray: the camera ray of its current sample, a shadow ray towards the light sample of the
+// vertex it stands on, or the BSDF-sampled ray leaving that vertex. All shading of a vertex — light sample, BSDF
+// evaluation towards it, MIS weight, BSDF sample with f and pdf — happens when the vertex is reached, so nothing but
+// (origin, two directions, f, pdf, throughput) stays in registers across the traversals; radiance and the pending
+// next-event contribution live in the lane's LDS slot.
+enum { P_START = 0, P_PRIMARY = 1, P_SHADOW = 2, P_BOUNCE = 3, P_DONE = 4 };
+
+struct PathLane {
+    int st, s, s_end, num_vertices;
+    int bounce_valid;                 // a BSDF-sampled ray follows the shadow ray
+    unsigned long long rng_state, rng_inc;
+    D3 org;                           // the vertex both pending rays leave (camera position for P_PRIMARY)
+    D3 dir_b;                         // closest-hit ray: camera ray or BSDF-sampled direction
+    D3 dir_s; double tfar_s;          // shadow ray
+    double eta_scale;
+};
+// LDS slot layout (doubles, stride kBlock): 0..2 radiance of the current sample, 3..5 pending next-event contribution,
+// 6..8 f*|cos| and 9 the solid-angle pdf of dir_b at org, 10..12 throughput — everything that is cold while a ray is
+// in flight ("manual spills" that cost an LDS access instead of a scratch round trip).
+constexpr int kPathPrivDoubles = 13;
+struct PathPriv {
+    double *slot; int stride;
+    GD D3 radiance() const { return mk(slot[0], slot[stride], slot[2 * stride]); }
+    GD void set_radiance(D3 v) { slot[0] = v.x; slot[stride] = v.y; slot[2 * stride] = v.z; }
+    GD D3 nee() const { return mk(slot[3 * stride], slot[4 * stride], slot[5 * stride]); }
+    GD void set_nee(D3 v) { slot[3 * stride] = v.x; slot[4 * stride] = v.y; slot[5 * stride] = v.z; }
+    GD D3 f() const { return mk(slot[6 * stride], slot[7 * stride], slot[8 * stride]); }
+    GD double pdf() const { return slot[9 * stride]; }
+    GD void set_f_pdf(D3 v, double p) { slot[6 * stride] = v.x; slot[7 * stride] = v.y; slot[8 * stride] = v.z; slot[9 * stride] = p; }
+    GD D3 throughput() const { return mk(slot[10 * stride], slot[11 * stride], slot[12 * stride]); }
+    GD void set_throughput(D3 v) { slot[10 * stride] = v.x; slot[11 * stride] = v.y; slot[12 * stride] = v.z; }
+};
+
+GD bool path_lane_tracing(int st) { return st == P_PRIMARY || st == P_SHADOW || st == P_BOUNCE; }
+
+template <class TC>
+GD void path_trace_pending(const DevSceneView &sv, const TraceCtx &tx, const PathLane &L, Trav &tv, int keep_frac, int search_frac, TraceCounters &tc) {
+    const bool pending = path_lane_tracing(L.st) && tv.cur != kTravDone;
+    const unsigned long long m = __ballot(pending);
+    if (m == 0ull) return;
+    const int stop_below = (__popcll(m) * keep_frac) >> 8;
+    if (pending) {
+        const bool shadow = (L.st == P_SHADOW);
+        const float tnear = (L.st == P_PRIMARY) ? 0.0f : (float)sv.isect_eps;        // shadow epsilon == intersection epsilon
+        const float tfar = shadow ? (float)L.tfar_s : __builtin_huge_valf();
+        trav_run<TC>(sv, tx, L.org, shadow ? L.dir_s : L.dir_b, tnear, tfar, tv, stop_below, search_frac, tc, shadow);
+    }
+}
+
+// One step of a lane whose pending ray is finished (or that needs its first ray).
+template <bool LAMBERT>
+GD void path_lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, int x, int y, unsigned long long base,
+                       PathLane &L, Trav &tv, PathPriv &lp, double *acc_slot, int acc_stride, LaneCounters &lc) {
+    const DevCamera &cam = sv.cam;
+    const int w = cam.width, h = cam.height;
+    const int st0 = L.st;
+    bool shade = false, finish = false, new_sample = (st0 == P_START);
+    Vertex nv;
+    D3 arriving = L.dir_b;                       // direction of the closest-hit ray that reached nv
+    if (st0 == P_PRIMARY || st0 == P_BOUNCE) {
+        lc.rays++;
+        const bool hit = tv.best.gid >= 0;
+        Ray ray; ray.org = L.org; ray.dir = L.dir_b; ray.tnear = 0; ray.tfar = __builtin_huge_val();
+        if (hit) make_vertex(sv, tx.tris, tx.need_uv, ray, tv.best, 0.0, (st0 == P_PRIMARY) ? 0.25 / (double)max(w, h) : 0.0, nv);
+        if (st0 == P_PRIMARY) {
+            if (!hit) { lp.set_radiance(splat(0)); finish = true; }                               // :31-43
+            else {
+                lp.set_throughput(splat(1.0)); L.eta_scale = 1.0; L.num_vertices = 3;
+                lp.set_radiance((nv.light_id >= 0) ? emission(sv, nv, -L.dir_b) : splat(0));       // :76-79
+                if (loop_allows(max_depth, 3)) shade = true; else finish = true;
+            }
+        } else {
+            double G = 1.0;
+            if (hit) { const D3 dl = nv.position - L.org; G = fabs(dot(L.dir_b, nv.gn)) / dot(dl, dl); }
+            const D3 f_b = lp.f();
+            const D3 T = lp.throughput();
+            const double p2 = lp.pdf() * G;                                                        // :268 (pdf > 0 was checked at the vertex)
+            if (hit && nv.light_id >= 0) {                                                         // :286-306, no MIS weight
+                const D3 Le = emission(sv, nv, -L.dir_b);
+                D3 C2 = G * f_b * Le;
+                C2 = C2 / p2;
+                lp.set_radiance(lp.radiance() + T * C2);
+            }
+            if (!hit) finish = true;                                                               // :327-329
+            else {
+                double rr_prob = 1;
+                bool stop = false;
+                if (L.num_vertices - 1 >= sv.rr_depth) {                                           // :333-340
+                    rr_prob = fmin(maxc((1 / L.eta_scale) * T), 0.95);
+                    Pcg r; r.state = L.rng_state; r.inc = L.rng_inc;
+                    const double u = pcg_real(r); L.rng_state = r.state;
+                    if (u > rr_prob) stop = true;
+                }
+                if (stop) finish = true;
+                else {
+                    lp.set_throughput(T * (G * f_b) / (p2 * rr_prob));                             // :344
+                    L.num_vertices++;
+                    if (loop_allows(max_depth, L.num_vertices)) shade = true; else finish = true;
+                }
+            }
+        }
+    } else if (st0 == P_SHADOW) {
+        lc.rays++;
+        if (!(tv.best.gid >= 0)) lp.set_radiance(lp.radiance() + lp.nee());                       // unoccluded: :178
+        if (L.bounce_valid) { L.st = P_BOUNCE; trav_init(sv, tv, __builtin_huge_val()); }
+        else finish = true;
+    }
+    if (shade) {                                  // all the work of one loop iteration at vertex nv (:113-266)
+        lc.bounces++;
+        Pcg rng; rng.state = L.rng_state; rng.inc = L.rng_inc;
+        const D3 dir_view = -arriving;
+        // ---- next-event estimation
+        D2 light_uv; light_uv.x = pcg_real(rng); light_uv.y = pcg_real(rng);
+        const double light_w = pcg_real(rng);
+        const double shape_w = pcg_real(rng);
+        const int light_id = table_sample(sv.light_cdf, sv.num_lights, light_w);
+        const DevLight &light = sv.lights[light_id];
+        const PointNormal pl = sample_point_on_light(sv, light, nv.position, light_uv, shape_w);
+        const D3 dl = pl.position - nv.position;
+        const double dist2 = dot(dl, dl);
+        const D3 dir_light = normalize(dl);
+        D3 nee = splat(0);
+        {
+            // the contribution assuming the shadow ray is unoccluded; the ray is traced only if it is non-zero
+            const double G = fmax(-dot(dir_light, pl.normal), 0.0) / dist2;
+            const double p1 = sv.light_pmf[light_id] * pdf_point_on_light(sv, light, pl, nv.position);
+            if (G > 0 && p1 > 0) {
+                D3 f; double p2;
+                mat_eval_pdf<LAMBERT>(sv, tx, nv, dir_view, dir_light, f, p2);
+                const D3 Le = (dot(pl.normal, -dir_light) <= 0) ? splat(0) : mk(light.intensity[0], light.intensity[1], light.intensity[2]);
+                D3 C1 = G * f * Le;
+                p2 *= G;
+                const double w1 = (p1 * p1) / (p1 * p1 + p2 * p2);
+                C1 = C1 / p1;
+                nee = lp.throughput() * C1 * w1;
+            }
+        }
+        // ---- BSDF sampling
+        D2 ruv; ruv.x = pcg_real(rng); ruv.y = pcg_real(rng);
+        const double rw = pcg_real(rng);
+        L.rng_state = rng.state;
+        BsdfSample bs;
+        L.bounce_valid = 0;
+        if (mat_sample<LAMBERT>(sv, tx, nv, dir_view, ruv, rw, bs)) {                              // :200-203
+            if (bs.eta != 0) L.eta_scale /= (bs.eta * bs.eta);
+            D3 f; double pdf;
+            mat_eval_pdf<LAMBERT>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
+            if (pdf > 0) { L.bounce_valid = 1; L.dir_b = bs.dir_out; lp.set_f_pdf(f, pdf); }      // :263-266
+        }
+        L.org = nv.position;
+        const bool want_shadow = (nee.x != 0 || nee.y != 0 || nee.z != 0);
+        if (want_shadow) {
+            lp.set_nee(nee);
+            L.dir_s = dir_light; L.tfar_s = (1 - sv.isect_eps) * sqrt(dist2);
+            L.st = P_SHADOW; trav_init(sv, tv, L.tfar_s);
+        } else if (L.bounce_valid) { L.st = P_BOUNCE; trav_init(sv, tv, __builtin_huge_val()); }
+        else finish = true;
+    }
+    if (finish) {                                 // src/render.cpp:107-109
+        const D3 r = lp.radiance();
+        path_count_nonfinite(r, lc);
+        __hip_atomic_fetch_add(acc_slot, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(acc_slot + acc_stride, r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(acc_slot + 2 * acc_stride, r.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        L.s++;
+        if (L.s >= L.s_end) L.st = P_DONE; else new_sample = true;
+    }
+    if (new_sample) {
+        Pcg r = pcg_init(base + (unsigned long long)L.s);
+        const double rx = pcg_real(r);                                                             // :21-22, x first
+        const double ry = pcg_real(r);
+        L.rng_state = r.state; L.rng_inc = r.inc;
+        const Ray pr = sample_primary(cam, (x + rx) / w, (y + ry) / h);
+        L.org = pr.org; L.dir_b = pr.dir;
+        L.st = P_PRIMARY; trav_init(sv, tv, __builtin_huge_val());
+    }
+}
+
+template <bool LAMBERT, bool LDS_SCENE>
+__global__ __launch_bounds__(kBlock, 2) void gdpt_path_persistent(DevSceneView sv, KernelArgs a) {
+    constexpr int kLevels = LDS_SCENE ? kLdsSceneLevels : GDPT_BVH_MAX_DEPTH;
+    __shared__ int s_stack[kLevels * kBlock];
+    __shared__ __attribute__((aligned(16))) unsigned char s_scene[LDS_SCENE ? kLdsSceneBytes : 16];
+    __shared__ double s_acc[3 * kBlock];
+    __shared__ double s_priv[kPathPrivDoubles * kBlock];
+    const int tid = threadIdx.x;
+    TraceCtx tx = setup_trace<LDS_SCENE, true>(sv, s_scene, s_stack, tid, kBlock, a.count != 0);
+    const int W = sv.cam.width;
+    double *acc_slot = s_acc + tid;
+    acc_slot[0] = 0; acc_slot[kBlock] = 0; acc_slot[2 * kBlock] = 0;
+    PathPriv lp; lp.slot = s_priv + tid; lp.stride = kBlock;
+    LaneCounters lc = {0, 0, 0};
+    TraceCounters tc = {0, 0, 0, 0, 0, 0};
+    PathLane L;
+    Trav tv;
+    trav_init(sv, tv, __builtin_huge_val());
+    L.s = 0; L.s_end = 0; L.st = P_DONE; L.num_vertices = 0; L.bounce_valid = 0; L.rng_state = 0; L.rng_inc = 1;
+    L.org = L.dir_b = L.dir_s = splat(0); L.tfar_s = 0; L.eta_scale = 1;
+    int x = 0, y = 0;
+    unsigned long long base = 0;
+    long long my_item = -1;
+    WaveQueue wq;
+    for (;;) {
+        const bool idle = (L.st == P_DONE);
+        if (idle && my_item >= 0) {                     // item finished: publish its three sums (32-byte record)
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            d2 *dst = (d2 *)(a.partials + (size_t)my_item * 4);
+            dst[0] = d2{acc_slot[0], acc_slot[kBlock]}; dst[1] = d2{acc_slot[2 * kBlock], 0.0};
+            acc_slot[0] = 0; acc_slot[kBlock] = 0; acc_slot[2 * kBlock] = 0;
+            my_item = -1;
+        }
+        const long long got_item = wq.take(a, idle, tid);
+        if (got_item >= 0) {
+            my_item = got_item;
+            int s0, s1;
+            const bool inside = item_to_pixel(a, W, (unsigned)my_item, x, y, s0, s1);
+            base = ((unsigned long long)y * W + x) * (unsigned long long)a.spp;
+            L.s = s0; L.s_end = s1;
+            L.st = (inside && s0 < s1) ? P_START : P_DONE;
+        }
+        if (!__any(L.st != P_DONE)) { if (wq.exhausted) break; else continue; }
+        path_trace_pending<TraceCfg<true, true, !LDS_SCENE>>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
+        if (L.st == P_START || (path_lane_tracing(L.st) && tv.cur == kTravDone)) {
+            if (tx.count) { tc.lane_steps++; if (wave_leader()) tc.wave_steps++; }
+            path_lane_step<LAMBERT>(sv, tx, a.max_depth, x, y, base, L, tv, lp, acc_slot, kBlock, lc);
+        }
+    }
+    flush_counters(a, lc, tc, a.count != 0);
+}
+
+// Sums the per-chunk records of every pixel in chunk order and divides by spp (src/render.cpp:110).
+__global__ __launch_bounds__(256) void gdpt_path_reduce(KernelArgs a, int W) {
+    const long long nslots = a.num_items >> a.log2c;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long idx = t >> 2;
+    const int j = (int)(t & 3);
+    if (idx >= nslots || j == 3) return;
+    int x, y, s0, s1;
+    if (!item_to_pixel(a, W, (unsigned)(idx << a.log2c), x, y, s0, s1)) return;
+    const int chunks = 1 << a.log2c;
+    const double *src = a.partials + ((size_t)(idx << a.log2c)) * 4 + j;
+    double v = 0;
+    for (int c = 0; c < chunks; c++) v += src[(size_t)c * 4];
+    a.img[((size_t)y * W + x) * 3 + j] = v / (double)a.spp;
+}
+
 } // namespace gd
 
 namespace gdpt {
 void launch_path(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, hipStream_t stream) {
     hipLaunchKernelGGL(gd::gdpt_path_eager, grid, dim3(gd::kBlock), 0, stream, sv, a);
+}
+void launch_path_persistent(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lambert, hipStream_t stream) {
+    if (lambert && lds) hipLaunchKernelGGL((gd::gdpt_path_persistent<true, true>), grid, dim3(gd::kBlock), 0, stream, sv, a);
+    else if (lambert) hipLaunchKernelGGL((gd::gdpt_path_persistent<true, false>), grid, dim3(gd::kBlock), 0, stream, sv, a);
+    else if (lds) hipLaunchKernelGGL((gd::gdpt_path_persistent<false, true>), grid, dim3(gd::kBlock), 0, stream, sv, a);
+    else hipLaunchKernelGGL((gd::gdpt_path_persistent<false, false>), grid, dim3(gd::kBlock), 0, stream, sv, a);
+    const long long nslots = a.num_items >> a.log2c;
+    hipLaunchKernelGGL(gd::gdpt_path_reduce, dim3((unsigned)((nslots * 4 + 255) / 256)), dim3(256), 0, stream, a, sv.cam.width);
 }
 void launch_tile_path(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream) {
     hipLaunchKernelGGL(gd::gdpt_path_tile_stream, grid, dim3(64), 0, stream, sv, a, ntx, nty);

@@ -65,7 +65,8 @@ def test_gpu_cbox_path_sample_stream(G, O, scene_tmp, w, h, spp):
     got, st = sc.path_render(spp, G.RNG_SAMPLE)
     want, ost = O.OracleScene(sd.ptr).path_render(spp, G.RNG_SAMPLE, threads=8)
     assert np.isfinite(got).all() and rel_l2(got, want) < TOL
-    assert st.samples == w * h * spp == ost.samples and st.bounces == ost.bounces and st.rays == ost.rays
+    # (the persistent kernel skips shadow rays whose contribution is zero anyway, so only the bounce count is comparable)
+    assert st.samples == w * h * spp == ost.samples and st.bounces == ost.bounces and st.rays <= ost.rays
     again, _ = sc.path_render(spp, G.RNG_SAMPLE)
     assert np.array_equal(got, again)
 
@@ -77,7 +78,7 @@ def test_gpu_cbox_path_tile_stream_and_bands(G, O, scene_tmp):
     sc = G.Scene(sd)
     got, st = sc.path_render(3, G.RNG_TILE)
     want, ost = O.OracleScene(sd.ptr).path_render(3, G.RNG_TILE, threads=4)
-    assert rel_l2(got, want) < TOL and st.bounces == ost.bounces
+    assert rel_l2(got, want) < TOL and st.bounces == ost.bounces and st.rays == ost.rays      # straight loop: every ray of the reference
     whole, _ = sc.path_render(4, G.RNG_SAMPLE)
     band = np.zeros_like(whole)
     for rows in ((0, 16), (16, 40)):
@@ -94,7 +95,7 @@ def test_gpu_sponza_path_sphere_light_and_textures(G, O, scene_tmp):
     got, st = G.Scene(sd).path_render(2, G.RNG_SAMPLE)
     want, ost = O.OracleScene(sd.ptr, use_bvh=True).path_render(2, G.RNG_SAMPLE, threads=8)
     assert rel_l2(got, want) < 1e-7
-    assert st.bounces == ost.bounces and st.rays == ost.rays
+    assert st.bounces == ost.bounces and st.rays <= ost.rays
 
 
 @pytest.mark.gpu
@@ -135,7 +136,22 @@ def test_gpu_path_mesh_and_sphere_emitters_with_disney_lobes(G, O):
     want, ost = O.OracleScene(desc).path_render(6, G.RNG_SAMPLE, threads=8)
     assert want.mean() > 0.01
     assert rel_l2(got, want) < 1e-7
-    assert st.bounces == ost.bounces and st.rays == ost.rays
+    assert st.bounces == ost.bounces and st.rays <= ost.rays
+
+
+@pytest.mark.gpu
+def test_gpu_path_persistent_and_straight_loop_agree(G, scene_tmp, monkeypatch):
+    """The lane machine and the straight per-sample loop are two schedules of the same arithmetic."""
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=40, height=24, integrator="path")
+    sc = G.Scene(G.parse_scene(xml))
+    ref, rst = sc.path_render(16, G.RNG_SAMPLE)
+    for env in ({"GDPT_FORCE_EAGER": "1"}, {"GDPT_NO_LDS_SCENE": "1"}, {"GDPT_LOG2K": "0"}, {"GDPT_KEEP_FRAC": "0", "GDPT_SEARCH_FRAC": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got, st = sc.path_render(16, G.RNG_SAMPLE)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert rel_l2(got, ref) < 1e-12 and st.bounces == rst.bounces, env
 
 
 @pytest.mark.gpu
