@@ -665,8 +665,8 @@ struct WaveQueue {
         const unsigned long long m_idle = __ballot(idle);
         if (m_idle) {
             if (next >= end && !exhausted) {
-                const long long left = a.num_items - seen_head;
-                long long want = left / ((long long)gridDim.x * (kBlock / 64) * 4);
+                const unsigned left = (unsigned)(a.num_items - seen_head);          // num_items < 2^32
+                long long want = (long long)(left / (gridDim.x * (unsigned)(kBlock / 64) * 4u));
                 const long long n_idle_now = __popcll(m_idle);
                 want = want > 64 ? 64 : (want < n_idle_now ? n_idle_now : want);
                 unsigned long long got = 0;

@@ -193,3 +193,31 @@ def test_gpu_cli_renders_path_scenes(G, scene_tmp, tmp_path):
     want, _ = G.Scene(G.parse_scene(xml)).path_render(4, G.RNG_SAMPLE)
     assert img.shape == (32, 48, 3)
     assert np.allclose(img, want, rtol=2e-3, atol=1e-4)             # fp16 storage
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rel,filt", [("veach_mi/mi.xml", None), ("pixel_filter_test/pixel_filter_test.xml", None),
+                                      ("pixel_filter_test/pixel_filter_test.xml", "box"), ("pixel_filter_test/pixel_filter_test.xml", "tent")])
+def test_gpu_reference_test_scenes(G, O, scene_tmp, rel, filt):
+    """The reference's own test scenes for this integrator: veach_mi (five sphere emitters of very different power over
+    RoughPlastic plates, `direct` = path with max_depth 2) and pixel_filter_test (checkerboard of scale 1000 under
+    Gaussian / box / tent pixel filters, src/filters/*.inl), Path and GradPath, against the oracle."""
+    xml = scene_variant(scene_tmp, rel, width=96, height=64)
+    if filt is not None:
+        text = open(xml).read()
+        import re
+        text = re.sub(r'<rfilter type="gaussian">.*?</rfilter>', f'<rfilter type="{filt}"/>', text, flags=re.S)
+        open(xml, "w").write(text)
+    sd = G.parse_scene(xml)
+    if filt is not None:
+        assert sd.desc.camera.filter_type == {"box": G.FILTER_BOX, "tent": G.FILTER_TENT}[filt]
+    sc = G.Scene(sd)
+    osc = O.OracleScene(sd.ptr, use_bvh=True)
+    got, st = sc.path_render(6, G.RNG_SAMPLE)
+    want, ost = osc.path_render(6, G.RNG_SAMPLE, threads=8)
+    assert want.mean() > 0 and rel_l2(got, want) < 1e-7 and st.bounces == ost.bounces
+    gb, gst = sc.render(4, G.RNG_SAMPLE)
+    ob, gost = osc.render(4, G.RNG_SAMPLE, threads=8)
+    for k in ("img", "cx0", "cy0", "cx1", "cy1"):
+        assert rel_l2(gb[k], ob[k]) < 1e-7, k
+    assert gst.bounces == gost.bounces
