@@ -120,6 +120,169 @@ void exr_rle_decode(const unsigned char *src, size_t src_len, std::vector<unsign
     for (size_t k = 0; k < n; k++) raw[k] = (k & 1) ? *t2++ : *t1++;
 }
 
+// ---- OpenEXR PIZ blocks (compression 4; the reference reads them through tinyexr, e.g. scenes/matpreview/envmap.exr) --
+// Format (OpenEXR ImfPizCompressor / ImfHuf / ImfWav, as published): u16 minNonZero, u16 maxNonZero, the bytes
+// [min..max] of a 8192-byte bitmap of the 16-bit values present, i32 length, then a Huffman stream — header im, iM,
+// table length, nBits, reserved (5 x u32), the 6-bit code lengths of symbols im..iM with zero runs (63: 8-bit count + 6;
+// 59..62: 2..5 zeros), canonical codes numbered from the longest length up, symbol iM = "repeat the previous value
+// n times" (8-bit n) — of the wavelet-transformed, LUT-compacted 16-bit words laid out channel by channel; each
+// channel (each 16-bit half of a 32-bit channel) is a 2-D hierarchical Haar-like transform, 14-bit or modulo-16-bit
+// basis depending on the largest LUT index.
+struct PizHuff {
+    static constexpr int kSymbols = (1 << 16) + 1;
+    int count[59] = {0};
+    long long first[59] = {0};
+    std::vector<int> order;        // symbols sorted by (length, index)
+    int start[60] = {0};           // offset of each length's symbols in `order`
+    void build(const std::vector<unsigned char> &len) {
+        for (int l = 0; l < 59; l++) count[l] = 0;
+        for (int s = 0; s < kSymbols; s++) count[len[(size_t)s]]++;
+        long long c = 0;
+        for (int l = 58; l > 0; l--) { first[l] = c; c = (c + count[l]) >> 1; }
+        start[0] = 0;
+        int acc = 0;
+        for (int l = 1; l < 60; l++) { start[l] = acc; if (l < 59) acc += count[l]; }
+        order.assign((size_t)acc, 0);
+        std::vector<int> fill(start, start + 59);
+        for (int s = 0; s < kSymbols; s++) { int l = len[(size_t)s]; if (l > 0) order[(size_t)fill[l]++] = s; }
+    }
+};
+struct PizBits {
+    const unsigned char *p, *end;
+    unsigned long long acc = 0; int n = 0; long long budget;     // budget: bits of the stream still unread
+    bool bit(int *b) {
+        if (budget <= 0) return false;
+        if (n == 0) { if (p >= end) return false; acc = *p++; n = 8; }
+        *b = (int)((acc >> (n - 1)) & 1u); n--; budget--;
+        return true;
+    }
+    bool bits(int k, unsigned *v) { unsigned r = 0; for (int i = 0; i < k; i++) { int b; if (!bit(&b)) return false; r = (r << 1) | (unsigned)b; } *v = r; return true; }
+};
+void piz_huf_uncompress(const unsigned char *src, size_t len, std::vector<uint16_t> &out) {
+    auto fail = []() { throw std::runtime_error("EXR: corrupt PIZ Huffman data"); };
+    if (len < 20) fail();
+    auto u32 = [&](size_t o) { return (uint32_t)src[o] | ((uint32_t)src[o + 1] << 8) | ((uint32_t)src[o + 2] << 16) | ((uint32_t)src[o + 3] << 24); };
+    const uint32_t im = u32(0), iM = u32(4), nbits = u32(12);
+    if (im >= (uint32_t)PizHuff::kSymbols || iM >= (uint32_t)PizHuff::kSymbols || im > iM) fail();
+    std::vector<unsigned char> lens((size_t)PizHuff::kSymbols, 0);
+    PizBits tb{src + 20, src + len};
+    tb.budget = (long long)(len - 20) * 8;
+    for (uint32_t s = im; s <= iM; s++) {
+        unsigned l;
+        if (!tb.bits(6, &l)) fail();
+        if (l == 63) { unsigned z; if (!tb.bits(8, &z)) fail(); z += 6; if (s + z > iM + 1) fail(); s += z - 1; }     // long zero run
+        else if (l >= 59) { unsigned z = l - 59 + 2; if (s + z > iM + 1) fail(); s += z - 1; }                          // short zero run
+        else lens[s] = (unsigned char)l;
+    }
+    PizHuff h;
+    h.build(lens);
+    const unsigned char *data = tb.p;           // the table is padded to a byte boundary
+    if ((long long)nbits > (long long)(src + len - data) * 8) fail();
+    PizBits br{data, src + len};
+    br.budget = (long long)nbits;
+    size_t o = 0;
+    while (br.budget > 0 && o < out.size()) {
+        long long code = 0;
+        int sym = -1;
+        for (int l = 1; l <= 58; l++) {
+            int b;
+            if (!br.bit(&b)) fail();
+            code = (code << 1) | b;
+            if (h.count[l] > 0 && code >= h.first[l] && code < h.first[l] + h.count[l]) { sym = h.order[(size_t)(h.start[l] + (int)(code - h.first[l]))]; break; }
+        }
+        if (sym < 0) fail();
+        if ((uint32_t)sym == iM) {                          // run-length code
+            unsigned run;
+            if (!br.bits(8, &run) || o == 0 || o + run > out.size()) fail();
+            const uint16_t prev = out[o - 1];
+            for (unsigned i = 0; i < run; i++) out[o++] = prev;
+        } else out[o++] = (uint16_t)sym;
+    }
+    if (o != out.size()) fail();
+}
+inline void piz_wdec14(uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) {
+    const int ls = (int16_t)l, hi = (int16_t)h;
+    const int ai = ls + (hi & 1) + (hi >> 1);
+    a = (uint16_t)(int16_t)ai; b = (uint16_t)(int16_t)(ai - hi);
+}
+inline void piz_wdec16(uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) {
+    const int m = l, d = h;
+    const int bb = (m - (d >> 1)) & 0xFFFF;
+    const int aa = (d + bb - 0x8000) & 0xFFFF;
+    b = (uint16_t)bb; a = (uint16_t)aa;
+}
+void piz_wav2_decode(uint16_t *in, int nx, int ox, int ny, int oy, uint16_t mx) {
+    const bool w14 = mx < (1 << 14);
+    const int n = nx > ny ? ny : nx;
+    int p = 1, p2;
+    while (p <= n) p <<= 1;
+    p >>= 1; p2 = p; p >>= 1;
+    auto dec = [&](uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) { if (w14) piz_wdec14(l, h, a, b); else piz_wdec16(l, h, a, b); };
+    while (p >= 1) {
+        uint16_t *py = in, *ey = in + (ptrdiff_t)oy * (ny - p2);
+        const int oy1 = oy * p, oy2 = oy * p2, ox1 = ox * p, ox2 = ox * p2;
+        uint16_t i00, i01, i10, i11;
+        for (; py <= ey; py += oy2) {
+            uint16_t *px = py, *ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t *p01 = px + ox1, *p10 = px + oy1, *p11 = p10 + ox1;
+                dec(*px, *p10, i00, i10);
+                dec(*p01, *p11, i01, i11);
+                dec(i00, i01, *px, *p01);
+                dec(i10, i11, *p10, *p11);
+            }
+            if (nx & p) { uint16_t *p10 = px + oy1; dec(*px, *p10, i00, *p10); *px = i00; }
+        }
+        if (ny & p) {
+            uint16_t *px = py, *ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) { uint16_t *p01 = px + ox1; dec(*px, *p01, i00, *p01); *px = i00; }
+        }
+        p2 = p; p >>= 1;
+    }
+}
+// chan_words[c]: 1 for HALF, 2 for FLOAT / UINT channels (in file order)
+void exr_piz_decode(const unsigned char *src, size_t src_len, std::vector<unsigned char> &raw, const std::vector<int> &chan_words, int w, int lines) {
+    if (src_len == raw.size()) { std::memcpy(raw.data(), src, src_len); return; }
+    auto fail = []() { throw std::runtime_error("EXR: corrupt PIZ block"); };
+    if (src_len < 4) fail();
+    const unsigned min_nz = src[0] | (src[1] << 8), max_nz = src[2] | (src[3] << 8);
+    size_t pos = 4;
+    std::vector<unsigned char> bitmap(8192, 0);
+    if (max_nz >= 8192) fail();
+    if (min_nz <= max_nz) {
+        if (pos + (max_nz - min_nz + 1) > src_len) fail();
+        std::memcpy(&bitmap[min_nz], src + pos, max_nz - min_nz + 1);
+        pos += max_nz - min_nz + 1;
+    }
+    std::vector<uint16_t> lut(65536, 0);
+    int k = 0;
+    for (int i = 0; i < 65536; i++) if (i == 0 || (bitmap[(size_t)i >> 3] & (1 << (i & 7)))) lut[(size_t)k++] = (uint16_t)i;
+    const uint16_t max_value = (uint16_t)(k - 1);
+    if (pos + 4 > src_len) fail();
+    const uint32_t hlen = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16) | ((uint32_t)src[pos + 3] << 24);
+    pos += 4;
+    if (hlen > src_len - pos) fail();
+    std::vector<uint16_t> tmp(raw.size() / 2);
+    piz_huf_uncompress(src + pos, hlen, tmp);
+    std::vector<size_t> chan_start(chan_words.size());
+    size_t off = 0;
+    for (size_t c = 0; c < chan_words.size(); c++) {
+        chan_start[c] = off;
+        for (int j = 0; j < chan_words[c]; j++) piz_wav2_decode(tmp.data() + off + j, w, chan_words[c], lines, w * chan_words[c], max_value);
+        off += (size_t)w * lines * chan_words[c];
+    }
+    if (off != tmp.size()) fail();
+    for (auto &v : tmp) v = lut[v];
+    unsigned char *o = raw.data();
+    std::vector<size_t> cursor = chan_start;
+    for (int y = 0; y < lines; y++)
+        for (size_t c = 0; c < chan_words.size(); c++) {
+            const size_t n = (size_t)w * chan_words[c];
+            std::memcpy(o, tmp.data() + cursor[c], n * 2);
+            o += n * 2; cursor[c] += n;
+        }
+}
+
 // RGB half-float scanline file, channels B, G, R. Like tinyexr's SaveEXR (which the reference calls with fp16 output,
 // src/image.cpp:155-171): no compression when both extents are < 16, otherwise ZIP in 16-scanline blocks.
 void write_exr_half(const std::string &filename, int w, int h, const double *rgb) {
@@ -170,7 +333,7 @@ void write_exr_half(const std::string &filename, int w, int h, const double *rgb
     ofs.write((const char *)b.data(), (std::streamsize)b.size());
 }
 
-// Scanline OpenEXR reader: single part, compression NONE / RLE / ZIPS / ZIP, HALF / FLOAT / UINT channels.
+// Scanline OpenEXR reader: single part, compression NONE / RLE / ZIPS / ZIP / PIZ, HALF / FLOAT / UINT channels.
 // Returns what tinyexr's LoadEXR hands the reference (src/image.cpp:56-72,109-127): the R, G, B channels as fp32
 // (a single-channel file is replicated to all three).
 void read_exr_rgb(const std::string &filename, int *width, int *height, std::vector<float> *rgb) {
@@ -223,7 +386,8 @@ void read_exr_rgb(const std::string &filename, int *width, int *height, std::vec
     int lines_per_block;
     if (compression == 0 || compression == 1 || compression == 2) lines_per_block = 1;
     else if (compression == 3) lines_per_block = 16;
-    else throw std::runtime_error("Unsupported image format: OpenEXR compression " + std::to_string(compression) + " (NONE, RLE, ZIPS, ZIP are read): " + filename);
+    else if (compression == 4) lines_per_block = 32;
+    else throw std::runtime_error("Unsupported image format: OpenEXR compression " + std::to_string(compression) + " (NONE, RLE, ZIPS, ZIP, PIZ are read): " + filename);
     size_t bytes_per_px = 0;
     for (auto &c : chans) bytes_per_px += (c.type == 1) ? 2 : 4;
     int ir = -1, ig = -1, ib = -1;
@@ -246,6 +410,11 @@ void read_exr_rgb(const std::string &filename, int *width, int *height, std::vec
         std::vector<unsigned char> raw((size_t)lines * w * bytes_per_px);
         if (compression == 0) { if (len != raw.size()) throw std::runtime_error("Failure when loading image: bad OpenEXR block size: " + filename); std::memcpy(raw.data(), &f[pos], len); }
         else if (compression == 1) exr_rle_decode(&f[pos], len, raw);
+        else if (compression == 4) {
+            std::vector<int> words;
+            for (auto &c : chans) words.push_back(c.type == 1 ? 1 : 2);
+            exr_piz_decode(&f[pos], len, raw, words, w, lines);
+        }
         else exr_zip_decode(&f[pos], len, raw);
         size_t p = 0;
         for (int ly = 0; ly < lines; ly++)

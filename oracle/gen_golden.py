@@ -99,6 +99,13 @@ def gen_images():
             "pixels_crc32_as_read_by_reference": ref_seen["crc32"],
             "own_file_crc32": zlib.crc32(open(own_path, "rb").read()),   # this build's file, validated above by the reference reader
         }
+    # an EXR the reference's scenes use as input: PIZ-compressed environment map (scenes/matpreview/envmap.exr)
+    env = os.path.join(ROOT, "scenes", "matpreview", "envmap.exr")
+    seen = json.loads(subprocess.check_output([exe, "readexr", env]))
+    own = G.imread(env, 3)
+    assert zlib.crc32(own.astype(np.float32).tobytes()) == seen["crc32"]
+    doc["exr_inputs"] = {"matpreview/envmap.exr": {"width": seen["width"], "height": seen["height"], "pixels_crc32": seen["crc32"],
+                                                  "mean": own.mean(axis=(0, 1)).tolist()}}
     # the reference's own renders (fp16 + ZIP EXR written by lajolla): coarse statistics for end-to-end sanity checks
     doc["reference_renders"] = {}
     for rel in ("cbox_gdpt/cb_16.exr", "cbox_gdpt/cb_4.exr", "cbox_gdpt/cb_1.exr", "gdpt_renders/tmp_gdpt_0.04.exr",

@@ -108,6 +108,19 @@ def test_exr_against_reference_written_files(G, tmp_path):
         assert np.array_equal(G.imread(str(own), 3), seen)
 
 
+def test_piz_compressed_exr_matches_the_reference_reader(G):
+    """scenes/matpreview/envmap.exr (PIZ: wavelet + Huffman, the environment map of the reference's Disney / matpreview
+    scenes) through the build's own reader == the pixels tinyexr's LoadEXR hands the reference (CRC-32 of fp32 RGB)."""
+    import os
+    import zlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rec = _golden()["exr_inputs"]["matpreview/envmap.exr"]
+    a = G.imread(os.path.join(root, "scenes", "matpreview", "envmap.exr"), 3)
+    assert a.shape == (rec["height"], rec["width"], 3)
+    assert zlib.crc32(a.astype(np.float32).tobytes()) == rec["pixels_crc32"]
+    assert np.allclose(a.mean(axis=(0, 1)), rec["mean"], rtol=1e-12)
+
+
 def test_jpeg_decoder_matches_the_reference_decoder(G):
     """Every sponza texture through the build's baseline JPEG decoder == what the reference's imread3 / imread1
     (stb_image v2.27 as vendored there) return: CRC-32 of the fp32 texels, generated by oracle/ref_img.cpp."""
@@ -154,7 +167,8 @@ def test_decoders_reject_corrupt_input_without_crashing(G, tmp_path):
     G.imwrite(str(exr_path), ramp(33, 40) * 4 - 1)
     exr = exr_path.read_bytes()
     outcomes = {"ok": 0, "rejected": 0}
-    for kind, blob in (("jpg", jpg), ("exr", exr)):
+    piz = open(os.path.join(root, "scenes", "matpreview", "envmap.exr"), "rb").read()
+    for kind, blob in (("jpg", jpg), ("exr", exr), ("piz.exr", piz)):
         for it in range(120):
             b = bytearray(blob)
             mode = it % 3
