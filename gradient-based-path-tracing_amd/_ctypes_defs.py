@@ -47,6 +47,11 @@ class GdptCamera(C.Structure):
                 ("filter_param", C.c_double)]
 
 
+class GdptEnvmap(C.Structure):
+    _fields_ = [("light_id", C.c_int32), ("image_id", C.c_int32), ("scale", C.c_double),
+                ("to_world", C.c_double * 16), ("to_local", C.c_double * 16)]
+
+
 class GdptSceneDesc(C.Structure):
     _fields_ = [("camera", GdptCamera),
                 ("integrator", C.c_int32), ("samples_per_pixel", C.c_int32),
@@ -55,7 +60,8 @@ class GdptSceneDesc(C.Structure):
                 ("num_lights", C.c_int32), ("num_images", C.c_int32),
                 ("materials", C.POINTER(GdptMaterial)), ("shapes", C.POINTER(GdptShape)),
                 ("lights", C.POINTER(GdptLight)), ("images", C.POINTER(GdptImage)),
-                ("output_filename", C.c_char * 256), ("has_envmap", C.c_int32), ("_pad", C.c_int32)]
+                ("output_filename", C.c_char * 256), ("has_envmap", C.c_int32), ("_pad", C.c_int32),
+                ("envmap", GdptEnvmap)]
 
 
 class GdptRenderParams(C.Structure):

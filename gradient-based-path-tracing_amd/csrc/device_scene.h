@@ -110,6 +110,12 @@ struct DevSceneView {
     const double *light_tri_cdf;
     const double *light_tri_pos;            // 9 doubles per emitter triangle: v0, v1, v2
     const double *light_tri_nrm;            // 9 doubles per emitter triangle: n0, n1, n2 (zeros when the mesh has none)
+    // environment map (Envmap, src/lights/envmap.inl): lat-long image + its TableDist2D (src/table_dist.cpp:40-150)
+    int32_t has_envmap, env_light_id, env_image_id, env_pad;
+    int32_t env_w, env_h;
+    double env_scale;
+    double env_to_world[16], env_to_local[16];
+    const double *env_cdf_rows, *env_pdf_rows, *env_cdf_marginals, *env_pdf_marginals;
     int32_t num_nodes, num_nodes4, num_prims, num_tris, num_spheres;
     int32_t num_materials, num_lights, num_images;
     int32_t max_depth, rr_depth;

@@ -225,6 +225,8 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     for (int l = 0; l < desc->num_lights; l++) for (int k = 0; k < 3; k++) light_intensity.push_back(desc->lights[l].intensity[k]);
 
     // ---- Integrator::Path emitter tables (same formulas and operation order as the reference) ----
+    int env_power_slot = -1;
+    std::vector<double> light_power;
     std::vector<DevLight> dlights;
     std::vector<double> light_pmf, light_cdf, light_tri_cdf, light_tri_pos, light_tri_nrm;
     auto table_1d = [](const std::vector<double> &f, std::vector<double> &pmf, std::vector<double> &cdf) {   // src/table_dist.cpp:3-25
@@ -244,6 +246,11 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
         std::vector<double> power;
         for (int l = 0; l < desc->num_lights; l++) {
             const GdptLight &lt = desc->lights[l];
+            if (lt.shape_id < 0 && desc->has_envmap && l == desc->envmap.light_id) {      // environment map: power filled in below
+                dlights.push_back(DevLight{});
+                power.push_back(0.0);
+                continue;
+            }
             if (lt.shape_id < 0 || lt.shape_id >= desc->num_shapes) throw std::runtime_error("gdpt_scene_upload: light without a shape");
             const GdptShape &sh = desc->shapes[lt.shape_id];
             DevLight dl{};
@@ -274,7 +281,8 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
             power.push_back(lum * dl.area * 3.14159265358979323846);                              // diffuse_area_light.inl:1-3
             dlights.push_back(dl);
         }
-        if (!power.empty()) table_1d(power, light_pmf, light_cdf);
+        env_power_slot = desc->has_envmap ? desc->envmap.light_id : -1;
+        light_power = power;
     }
 
     DevSceneView &v = sc->view;
@@ -296,7 +304,6 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     v.images = sc->keep(upload(images));
     v.texels = sc->keep(upload(texels));
     v.lights = sc->keep(upload(dlights));
-    v.light_pmf = sc->keep(upload(light_pmf)); v.light_cdf = sc->keep(upload(light_cdf));
     v.light_tri_cdf = sc->keep(upload(light_tri_cdf));
     v.light_tri_pos = sc->keep(upload(light_tri_pos)); v.light_tri_nrm = sc->keep(upload(light_tri_nrm));
     sc->has_envmap = desc->has_envmap != 0;
@@ -314,6 +321,74 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     double dx = (double)ub[0] - (double)lb[0], dy = (double)ub[1] - (double)lb[1], dz = (double)ub[2] - (double)lb[2];
     double radius = prims.empty() ? 0.0 : std::sqrt(dx * dx + dy * dy + dz * dz) / 2;
     v.isect_eps = std::min(radius * 1e-5, 0.01);
+
+    // ---- environment map (Integrator::Path): TableDist2D over luminance * sin(elevation) of the level-0 image
+    // (init_sampling_dist, src/lights/envmap.inl:66-83; make_table_dist_2d, src/table_dist.cpp:40-112), its power
+    // (envmap.inl:1-5) and only then the light selection table (src/scene.cpp:44-53)
+    v.has_envmap = 0; v.env_light_id = -1;
+    if (desc->has_envmap) {
+        const GdptEnvmap &e = desc->envmap;
+        if (e.image_id < 0 || e.image_id >= desc->num_images || desc->images[e.image_id].channels != 3)
+            throw std::runtime_error("gdpt_scene_upload: environment map without a 3-channel image");
+        const GdptImage &im = desc->images[e.image_id];
+        const int w = im.width, h = im.height;
+        auto texel = [&](int x, int y) { const double *p = im.texels + ((size_t)y * w + x) * 3; return p; };
+        auto modulo = [](int a, int b) { int r = a % b; return r < 0 ? r + b : r; };
+        std::vector<double> f((size_t)w * h);
+        size_t i = 0;
+        for (int y = 0; y < h; y++) {
+            const double vv = (y + 0.5) / (double)h;
+            const double sin_elevation = std::sin(3.14159265358979323846 * vv);
+            for (int x = 0; x < w; x++) {
+                const double uu = (x + 0.5) / (double)w;
+                // lookup(mipmap, u, v, 0): bilinear at level 0 with repeat wrap (src/mipmap.h:51-72)
+                double u = uu * w - 0.5, vq = vv * h - 0.5;
+                int ufi = modulo((int)u, w), vfi = modulo((int)vq, h);
+                int uci = modulo(ufi + 1, w), vci = modulo(vfi + 1, h);
+                double u_off = u - ufi, v_off = vq - vfi;
+                double rgb[3];
+                for (int c = 0; c < 3; c++)
+                    rgb[c] = texel(ufi, vfi)[c] * (1 - u_off) * (1 - v_off) + texel(ufi, vci)[c] * (1 - u_off) * v_off +
+                             texel(uci, vfi)[c] * u_off * (1 - v_off) + texel(uci, vci)[c] * u_off * v_off;
+                f[i++] = (rgb[0] * 0.212671 + rgb[1] * 0.715160 + rgb[2] * 0.072169) * sin_elevation;
+            }
+        }
+        std::vector<double> cdf_rows((size_t)h * (w + 1)), pdf_rows((size_t)h * w), cdf_m((size_t)h + 1), pdf_m((size_t)h);
+        for (int y = 0; y < h; y++) {
+            double *cdf = &cdf_rows[(size_t)y * (w + 1)];
+            cdf[0] = 0;
+            for (int x = 0; x < w; x++) cdf[x + 1] = cdf[x] + f[(size_t)y * w + x];
+            const double integral = cdf[w];
+            if (integral > 0) {
+                for (int x = 0; x < w; x++) cdf[x] /= integral;
+                for (int x = 0; x < w; x++) pdf_rows[(size_t)y * w + x] = f[(size_t)y * w + x] / integral;
+            } else {
+                for (int x = 0; x < w; x++) { pdf_rows[(size_t)y * w + x] = 1.0 / (double)w; cdf[x] = (double)x / (double)w; }
+                cdf[w] = 1;
+            }
+        }
+        cdf_m[0] = 0;
+        for (int y = 0; y < h; y++) cdf_m[(size_t)y + 1] = cdf_m[(size_t)y] + cdf_rows[(size_t)y * (w + 1) + w];
+        const double total_values = cdf_m.back();
+        if (total_values > 0) {
+            for (int y = 0; y < h; y++) cdf_m[(size_t)y] /= total_values;
+            cdf_m[(size_t)h] = 1;
+            for (int y = 0; y < h; y++) pdf_m[(size_t)y] = cdf_rows[(size_t)y * (w + 1) + w] / total_values;
+        } else {
+            for (int y = 0; y < h; y++) { pdf_m[(size_t)y] = 1.0 / (double)h; cdf_m[(size_t)y] = (double)y / (double)h; }
+            cdf_m[(size_t)h] = 1;
+        }
+        for (int y = 0; y < h; y++) cdf_rows[(size_t)y * (w + 1) + w] = 1;
+        v.has_envmap = 1; v.env_light_id = e.light_id; v.env_image_id = e.image_id; v.env_w = w; v.env_h = h; v.env_scale = e.scale;
+        std::memcpy(v.env_to_world, e.to_world, sizeof(v.env_to_world));
+        std::memcpy(v.env_to_local, e.to_local, sizeof(v.env_to_local));
+        v.env_cdf_rows = sc->keep(upload(cdf_rows)); v.env_pdf_rows = sc->keep(upload(pdf_rows));
+        v.env_cdf_marginals = sc->keep(upload(cdf_m)); v.env_pdf_marginals = sc->keep(upload(pdf_m));
+        if (env_power_slot >= 0 && env_power_slot < (int)light_power.size())
+            light_power[(size_t)env_power_slot] = 3.14159265358979323846 * radius * radius * total_values / ((double)w * (double)h);
+    }
+    if (!light_power.empty()) table_1d(light_power, light_pmf, light_cdf);
+    v.light_pmf = sc->keep(upload(light_pmf)); v.light_cdf = sc->keep(upload(light_cdf));
 
     ck(hipMalloc((void **)&sc->d_counters, sizeof(gdpt::RenderCounters)), "hipMalloc(counters)");
     ck(hipMalloc((void **)&sc->d_queue, sizeof(unsigned long long)), "hipMalloc(queue)");
@@ -400,7 +475,6 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
 // Integrator::Path: enqueues one render of `img`; returns after enqueue unless stats are requested.
 void path_render_device_impl(GdptScene *sc, const GdptRenderParams *params, double *img, hipStream_t stream, GdptRenderStats *stats) {
     ck(hipSetDevice(sc->device), "hipSetDevice");
-    if (sc->has_envmap) throw std::runtime_error("gdpt_path_render: environment-map emitters are not supported by the Path entry points");
     if (sc->view.num_lights <= 0) throw std::runtime_error("gdpt_path_render: the scene has no emitter to sample");
     Band b = resolve(sc, params);
     if (b.spp <= 0) b.spp = sc->scene_spp;

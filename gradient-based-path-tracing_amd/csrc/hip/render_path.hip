@@ -90,6 +90,66 @@ GD double pdf_point_on_light(const DevSceneView &sv, const DevLight &lt, const P
     return pdf_solid_angle * fabs(dot(pt.normal, dir)) / dot(dl, dl);
 }
 
+// ---- environment map (src/lights/envmap.inl) + TableDist2D (src/table_dist.cpp:114-150) ----
+GD int upper_bound_index(const double *a, int n, double u) {       // first index in [0, n) with a[i] > u, n if none
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] > u) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+GD D2 table2d_sample(const DevSceneView &sv, D2 rnd) {
+    const int w = sv.env_w, h = sv.env_h;
+    int y_offset = upper_bound_index(sv.env_cdf_marginals, h + 1, rnd.y) - 1;
+    y_offset = min(max(y_offset, 0), h - 1);
+    double dy = rnd.y - sv.env_cdf_marginals[y_offset];
+    const double hy = sv.env_cdf_marginals[y_offset + 1] - sv.env_cdf_marginals[y_offset];
+    if (hy > 0) dy /= hy;
+    const double *cdf = sv.env_cdf_rows + (size_t)y_offset * (w + 1);
+    int x_offset = upper_bound_index(cdf, w + 1, rnd.x) - 1;
+    x_offset = min(max(x_offset, 0), w - 1);
+    double dx = rnd.x - cdf[x_offset];
+    const double hx = cdf[x_offset + 1] - cdf[x_offset];
+    if (hx > 0) dx /= hx;
+    D2 uv; uv.x = (x_offset + dx) / w; uv.y = (y_offset + dy) / h;
+    return uv;
+}
+GD double table2d_pdf(const DevSceneView &sv, D2 xy) {
+    const int w = sv.env_w, h = sv.env_h;
+    const int x = (int)fmin(fmax(xy.x * w, 0.0), (double)(w - 1));
+    const int y = (int)fmin(fmax(xy.y * h, 0.0), (double)(h - 1));
+    return sv.env_pdf_marginals[y] * sv.env_pdf_rows[(size_t)y * w + x] * w * h;
+}
+GD D3 xform_vector16(const double *m, D3 v) {
+    return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+GD D2 envmap_uv(D3 local_dir) {
+    const double inv_two_pi = 1.0 / kTwoPi, inv_pi = 1.0 / kPi;
+    D2 uv; uv.x = atan2(local_dir.x, -local_dir.z) * inv_two_pi; uv.y = acos(fmin(fmax(local_dir.y, -1.0), 1.0)) * inv_pi;
+    if (uv.x < 0) uv.x += 1;
+    return uv;
+}
+// emission(envmap, view_dir, ...): view_dir points away from the light. The footprint the reference derives
+// (min(|du/dw|, dv/dw_y) with dv/dw_y < 0) is always negative, i.e. the lookup is always level 0 (envmap.inl:49-64).
+GD D3 envmap_emission(const DevSceneView &sv, D3 view_dir) {
+    const D3 local_dir = xform_vector16(sv.env_to_local, -view_dir);
+    const D2 uv = envmap_uv(local_dir);
+    const double lu = modulo_d(uv.x, 1.0), lv = modulo_d(uv.y, 1.0);
+    return mip_lookup_level(sv, sv.images[sv.env_image_id], lu, lv, 0) * sv.env_scale;
+}
+GD D3 envmap_sample_dir(const DevSceneView &sv, D2 rnd_uv) {                 // world_dir; point_on_light.normal = -world_dir
+    const D2 uv = table2d_sample(sv, rnd_uv);
+    const double azimuth = uv.x * (2 * kPi), elevation = uv.y * kPi;
+    const D3 local_dir = mk(sin(azimuth) * sin(elevation), cos(elevation), -cos(azimuth) * sin(elevation));
+    return xform_vector16(sv.env_to_world, local_dir);
+}
+GD double envmap_pdf(const DevSceneView &sv, D3 normal) {
+    const D3 local_dir = xform_vector16(sv.env_to_local, -normal);
+    const D2 uv = envmap_uv(local_dir);
+    const double cos_elevation = local_dir.y;
+    const double sin_elevation = sqrt(fmin(fmax(1 - cos_elevation * cos_elevation, 0.0), 1.0));
+    if (sin_elevation <= 0) return 0;
+    return table2d_pdf(sv, uv) / (2 * kPi * kPi * sin_elevation);
+}
+
 // One path_tracing call. Returns the sample's radiance.
 GD D3 path_sample(const DevSceneView &sv, const TraceCtx &tx, int max_depth, int x, int y, Pcg &rng, LaneCounters &lc, TraceCounters &tc) {
     const DevCamera &cam = sv.cam;
@@ -99,7 +159,8 @@ GD D3 path_sample(const DevSceneView &sv, const TraceCtx &tx, int max_depth, int
     Ray ray = sample_primary(cam, (x + rx) / w, (y + ry) / h);
     const double rd_spread = 0.25 / (double)max(w, h);                          // init_ray_differential, src/ray.h:33-35
     Vertex vertex;
-    if (!intersect_ctx<TraceHbm>(sv, tx, ray, rd_spread, vertex, lc, tc)) return splat(0);   // :31-43 (no environment map)
+    if (!intersect_ctx<TraceHbm>(sv, tx, ray, rd_spread, vertex, lc, tc))                       // :31-43
+        return sv.has_envmap ? envmap_emission(sv, -ray.dir) : splat(0);
     D3 radiance = splat(0), throughput = splat(1.0);
     double eta_scale = 1.0;
     if (vertex.light_id >= 0) radiance = radiance + throughput * emission(sv, vertex, -ray.dir);   // :76-79
@@ -113,10 +174,11 @@ GD D3 path_sample(const DevSceneView &sv, const TraceCtx &tx, int max_depth, int
         const double shape_w = pcg_real(rng);
         const int light_id = table_sample(sv.light_cdf, sv.num_lights, light_w);
         const DevLight &light = sv.lights[light_id];
-        const PointNormal pl = sample_point_on_light(sv, light, vertex.position, light_uv, shape_w);
+        const bool env_light = sv.has_envmap && light_id == sv.env_light_id;
         D3 C1 = splat(0);
         double w1 = 0;
-        {
+        if (!env_light) {
+            const PointNormal pl = sample_point_on_light(sv, light, vertex.position, light_uv, shape_w);
             double G = 0;
             const D3 dir_light = normalize(pl.position - vertex.position);
             const D3 dl = pl.position - vertex.position;
@@ -129,6 +191,23 @@ GD D3 path_sample(const DevSceneView &sv, const TraceCtx &tx, int max_depth, int
                 const D3 dir_view = -ray.dir;
                 const D3 f = bsdf_eval(sv, mat, dir_view, dir_light, vertex);
                 const D3 L = (dot(pl.normal, -dir_light) <= 0) ? splat(0) : mk(light.intensity[0], light.intensity[1], light.intensity[2]);
+                C1 = G * f * L;
+                double p2 = bsdf_pdf(sv, mat, dir_view, dir_light, vertex);
+                p2 *= G;
+                w1 = (p1 * p1) / (p1 * p1 + p2 * p2);
+                C1 = C1 / p1;
+            }
+        } else {                                                                // :151-160
+            const D3 dir_light = envmap_sample_dir(sv, light_uv);               // = -point_on_light.normal
+            double G = 0;
+            Ray shadow_ray; shadow_ray.org = vertex.position; shadow_ray.dir = dir_light;
+            shadow_ray.tnear = shadow_eps; shadow_ray.tfar = __builtin_huge_val();
+            if (!occluded_ctx<TraceHbm>(sv, tx, shadow_ray, lc, tc)) G = 1;
+            const double p1 = sv.light_pmf[light_id] * envmap_pdf(sv, -dir_light);
+            if (G > 0 && p1 > 0) {
+                const D3 dir_view = -ray.dir;
+                const D3 f = bsdf_eval(sv, mat, dir_view, dir_light, vertex);
+                const D3 L = envmap_emission(sv, -dir_light);
                 C1 = G * f * L;
                 double p2 = bsdf_pdf(sv, mat, dir_view, dir_light, vertex);
                 p2 *= G;
@@ -159,6 +238,14 @@ GD D3 path_sample(const DevSceneView &sv, const TraceCtx &tx, int max_depth, int
             D3 C2 = G * f * L;
             C2 = C2 / p2;
             radiance = radiance + throughput * C2;
+        }
+        else if (!hit && sv.has_envmap) {                                       // :307-325, WITH the MIS weight
+            const D3 L = envmap_emission(sv, -dir_bsdf);
+            D3 C2 = G * f * L;
+            const double p1 = sv.light_pmf[sv.env_light_id] * envmap_pdf(sv, -dir_bsdf);
+            const double w2 = (p2 * p2) / (p1 * p1 + p2 * p2);
+            C2 = C2 / p2;
+            radiance = radiance + throughput * C2 * w2;
         }
         if (!hit) break;                                                        // :327-329
         double rr_prob = 1;
@@ -309,7 +396,7 @@ GD void path_lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth
         Ray ray; ray.org = L.org; ray.dir = L.dir_b; ray.tnear = 0; ray.tfar = __builtin_huge_val();
         if (hit) make_vertex(sv, tx.tris, tx.need_uv, ray, tv.best, 0.0, (st0 == P_PRIMARY) ? 0.25 / (double)max(w, h) : 0.0, nv);
         if (st0 == P_PRIMARY) {
-            if (!hit) { lp.set_radiance(splat(0)); finish = true; }                               // :31-43
+            if (!hit) { lp.set_radiance(sv.has_envmap ? envmap_emission(sv, -L.dir_b) : splat(0)); finish = true; }   // :31-43
             else {
                 lp.set_throughput(splat(1.0)); L.eta_scale = 1.0; L.num_vertices = 3;
                 lp.set_radiance((nv.light_id >= 0) ? emission(sv, nv, -L.dir_b) : splat(0));       // :76-79
@@ -326,6 +413,14 @@ GD void path_lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth
                 D3 C2 = G * f_b * Le;
                 C2 = C2 / p2;
                 lp.set_radiance(lp.radiance() + T * C2);
+            }
+            else if (!hit && sv.has_envmap) {                                                      // :307-325, WITH the MIS weight
+                const D3 Le = envmap_emission(sv, -L.dir_b);
+                D3 C2 = G * f_b * Le;
+                const double p1 = sv.light_pmf[sv.env_light_id] * envmap_pdf(sv, -L.dir_b);
+                const double w2 = (p2 * p2) / (p1 * p1 + p2 * p2);
+                C2 = C2 / p2;
+                lp.set_radiance(lp.radiance() + T * C2 * w2);
             }
             if (!hit) finish = true;                                                               // :327-329
             else {
@@ -361,12 +456,16 @@ GD void path_lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth
         const double shape_w = pcg_real(rng);
         const int light_id = table_sample(sv.light_cdf, sv.num_lights, light_w);
         const DevLight &light = sv.lights[light_id];
-        const PointNormal pl = sample_point_on_light(sv, light, nv.position, light_uv, shape_w);
-        const D3 dl = pl.position - nv.position;
-        const double dist2 = dot(dl, dl);
-        const D3 dir_light = normalize(dl);
+        const bool env_light = sv.has_envmap && light_id == sv.env_light_id;
+        D3 dir_light;
+        double shadow_tfar;
         D3 nee = splat(0);
-        {
+        if (!env_light) {
+            const PointNormal pl = sample_point_on_light(sv, light, nv.position, light_uv, shape_w);
+            const D3 dl = pl.position - nv.position;
+            const double dist2 = dot(dl, dl);
+            dir_light = normalize(dl);
+            shadow_tfar = (1 - sv.isect_eps) * sqrt(dist2);
             // the contribution assuming the shadow ray is unoccluded; the ray is traced only if it is non-zero
             const double G = fmax(-dot(dir_light, pl.normal), 0.0) / dist2;
             const double p1 = sv.light_pmf[light_id] * pdf_point_on_light(sv, light, pl, nv.position);
@@ -376,6 +475,19 @@ GD void path_lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth
                 const D3 Le = (dot(pl.normal, -dir_light) <= 0) ? splat(0) : mk(light.intensity[0], light.intensity[1], light.intensity[2]);
                 D3 C1 = G * f * Le;
                 p2 *= G;
+                const double w1 = (p1 * p1) / (p1 * p1 + p2 * p2);
+                C1 = C1 / p1;
+                nee = lp.throughput() * C1 * w1;
+            }
+        } else {                                                                                   // :151-160: G = 1 if unoccluded
+            dir_light = envmap_sample_dir(sv, light_uv);
+            shadow_tfar = __builtin_huge_val();
+            const double p1 = sv.light_pmf[light_id] * envmap_pdf(sv, -dir_light);
+            if (p1 > 0) {
+                D3 f; double p2;
+                mat_eval_pdf<LAMBERT>(sv, tx, nv, dir_view, dir_light, f, p2);
+                D3 C1 = 1.0 * f * envmap_emission(sv, -dir_light);
+                p2 *= 1.0;
                 const double w1 = (p1 * p1) / (p1 * p1 + p2 * p2);
                 C1 = C1 / p1;
                 nee = lp.throughput() * C1 * w1;
@@ -397,7 +509,7 @@ GD void path_lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth
         const bool want_shadow = (nee.x != 0 || nee.y != 0 || nee.z != 0);
         if (want_shadow) {
             lp.set_nee(nee);
-            L.dir_s = dir_light; L.tfar_s = (1 - sv.isect_eps) * sqrt(dist2);
+            L.dir_s = dir_light; L.tfar_s = shadow_tfar;
             L.st = P_SHADOW; trav_init(sv, tv, L.tfar_s);
         } else if (L.bounce_valid) { L.st = P_BOUNCE; trav_init(sv, tv, __builtin_huge_val()); }
         else finish = true;

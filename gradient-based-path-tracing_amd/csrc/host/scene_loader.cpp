@@ -682,8 +682,28 @@ struct Builder {
             } else if (c.name == "emitter") {
                 std::string type = c.attr("type");
                 if (type == "envmap") {
-                    // Integrator::GradPath never evaluates the environment (src/path_tracing.h:982-985): ignored there;
-                    // the Path entry points refuse scenes that carry one.
+                    // src/parsers/parse_scene.cpp:1484-1508. Integrator::GradPath never evaluates the environment
+                    // (src/path_tracing.h:982-985); Integrator::Path samples it and looks it up.
+                    std::string filename;
+                    double scale = 1;
+                    M4 to_world = M4::identity();
+                    for (auto &gp : c.children) {
+                        const XmlNode &g = *gp;
+                        std::string n = g.attr("name");
+                        if (n == "filename") filename = parse_string(g.attr("value"), dm);
+                        else if (n == "toWorld" || n == "to_world") to_world = parse_transform(g, dm);
+                        else if (n == "scale") scale = parse_float(g.attr("value"), dm);
+                    }
+                    if (filename.empty()) fail("Filename unspecified for envmap.");
+                    GdptEnvmap &e = hs.desc.envmap;
+                    e.image_id = insert_image("__envmap_texture__", filename, 3);
+                    e.scale = scale;
+                    M4 to_local = inverse(to_world);
+                    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { e.to_world[4 * i + j] = to_world(i, j); e.to_local[4 * i + j] = to_local(i, j); }
+                    e.light_id = (int)hs.lights.size();
+                    GdptLight l{};
+                    l.shape_id = -1;
+                    hs.lights.push_back(l);
                     hs.desc.has_envmap = 1;
                 } else if (type == "point" || type == "directional") {
                     fail("emitter type '" + type + "' is outside the GradPath hot-path subset");

@@ -88,7 +88,8 @@ typedef struct GdptShape {
     const double *uvs;         /* 2*num_vertices or NULL */
 } GdptShape;
 
-typedef struct GdptLight {     /* DiffuseAreaLight, src/light.h; envmaps are ignored by GradPath (src/path_tracing.h:982-985) */
+typedef struct GdptLight {     /* DiffuseAreaLight (src/light.h), or the placeholder of the environment map (shape_id = -1,
+                                  its data is GdptSceneDesc::envmap) so that light ids keep the reference's parse order */
     int32_t shape_id;
     int32_t _pad;
     double intensity[3];
@@ -107,6 +108,13 @@ typedef struct GdptCamera {    /* src/camera.h:10-26 */
 
 enum { GDPT_INTEGRATOR_PATH = 5, GDPT_INTEGRATOR_GRADPATH = 7, GDPT_INTEGRATOR_OTHER = -1 }; /* src/scene.h:14-23 */
 
+typedef struct GdptEnvmap {    /* Envmap, src/light.h + src/lights/envmap.inl: lat-long image, uv = (azimuth/2pi, elevation/pi) */
+    int32_t light_id;          /* index into lights[] */
+    int32_t image_id;          /* 3-channel image */
+    double scale;
+    double to_world[16], to_local[16];   /* row-major; to_local = inverse(to_world) */
+} GdptEnvmap;
+
 typedef struct GdptSceneDesc {
     GdptCamera camera;
     int32_t integrator;
@@ -119,8 +127,10 @@ typedef struct GdptSceneDesc {
     const GdptLight *lights;
     const GdptImage *images;
     char output_filename[256]; /* film `filename`, default "image.exr" (src/parsers/parse_scene.cpp:15) */
-    int32_t has_envmap;        /* the XML holds an <emitter type="envmap">: ignored by GradPath, refused by the Path entry points */
+    int32_t has_envmap;        /* the XML holds an <emitter type="envmap">: ignored by GradPath (src/path_tracing.h:982-985),
+                                  sampled and looked up by the Path entry points */
     int32_t _pad;
+    GdptEnvmap envmap;         /* valid when has_envmap */
 } GdptSceneDesc;
 
 /* ---- render parameters ---- */
@@ -192,9 +202,9 @@ int gdpt_render_device(GdptScene *scene, const GdptRenderParams *params,
                        void *stream, GdptRenderStats *stats /* nullable */);
 
 /* ---- Integrator::Path (path_render, src/render.cpp:74-117 over path_tracing, src/path_tracing.h:13-348) ----
- * Unidirectional path tracing with next-event estimation + MIS for scenes lit by area emitters (meshes, spheres):
- * img = mean over spp of path_tracing(x, y). Same parameters, RNG schemes and stats as gdpt_render; scenes carrying
- * an environment map are refused (error status), as are scenes without emitters. */
+ * Unidirectional path tracing with next-event estimation + MIS for scenes lit by area emitters (meshes, spheres)
+ * and / or an environment map (src/lights/envmap.inl): img = mean over spp of path_tracing(x, y). Same parameters,
+ * RNG schemes and stats as gdpt_render; scenes without any emitter are refused (error status). */
 int gdpt_path_render(GdptScene *scene, const GdptRenderParams *params, double *img, GdptRenderStats *stats /* nullable */);
 int gdpt_path_render_device(GdptScene *scene, const GdptRenderParams *params, double *d_img,
                             void *stream, GdptRenderStats *stats /* nullable */);

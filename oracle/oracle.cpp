@@ -135,6 +135,10 @@ struct OracleScene {
     std::vector<Real> light_pmf, light_cdf;
     struct MeshTable { std::vector<Real> pmf, cdf; Real total_area = 0; };
     std::vector<MeshTable> mesh_tables;     // per shape (empty for non-emitters and spheres)
+    // environment map (src/lights/envmap.inl): TableDist2D over luminance * sin(elevation) of the level-0 image
+    struct Table2D { std::vector<Real> cdf_rows, pdf_rows, cdf_marginals, pdf_marginals; Real total_values = 0; int width = 0, height = 0; };
+    Table2D env_table;
+    Real bounds_radius = 0;                 // scene.bounds.radius (src/scene.cpp:29-34)
 };
 
 namespace {
@@ -1166,6 +1170,93 @@ int table_sample(const std::vector<Real> &pmf, const std::vector<Real> &cdf, Rea
     return std::min(std::max(int(ptr - cdf.data() - 1), 0), size - 1);
 }
 
+// make_table_dist_2d / sample / pdf, src/table_dist.cpp:40-150
+void make_table_2d(const std::vector<Real> &f, int width, int height, OracleScene::Table2D &t) {
+    t.width = width; t.height = height;
+    t.cdf_rows.assign((size_t)height * (width + 1), 0); t.pdf_rows.assign((size_t)height * width, 0);
+    for (int y = 0; y < height; y++) {
+        Real *cdf = &t.cdf_rows[(size_t)y * (width + 1)];
+        cdf[0] = 0;
+        for (int x = 0; x < width; x++) cdf[x + 1] = cdf[x] + f[(size_t)y * width + x];
+        Real integral = cdf[width];
+        if (integral > 0) {
+            for (int x = 0; x < width; x++) cdf[x] /= integral;
+            for (int x = 0; x < width; x++) t.pdf_rows[(size_t)y * width + x] = f[(size_t)y * width + x] / integral;
+        } else {
+            for (int x = 0; x < width; x++) { t.pdf_rows[(size_t)y * width + x] = Real(1) / Real(width); cdf[x] = Real(x) / Real(width); }
+            cdf[width] = 1;
+        }
+    }
+    t.cdf_marginals.assign((size_t)height + 1, 0); t.pdf_marginals.assign((size_t)height, 0);
+    for (int y = 0; y < height; y++) t.cdf_marginals[(size_t)y + 1] = t.cdf_marginals[(size_t)y] + t.cdf_rows[(size_t)y * (width + 1) + width];
+    t.total_values = t.cdf_marginals.back();
+    if (t.total_values > 0) {
+        for (int y = 0; y < height; y++) t.cdf_marginals[(size_t)y] /= t.total_values;
+        t.cdf_marginals[(size_t)height] = 1;
+        for (int y = 0; y < height; y++) t.pdf_marginals[(size_t)y] = t.cdf_rows[(size_t)y * (width + 1) + width] / t.total_values;
+    } else {
+        for (int y = 0; y < height; y++) { t.pdf_marginals[(size_t)y] = Real(1) / Real(height); t.cdf_marginals[(size_t)y] = Real(y) / Real(height); }
+        t.cdf_marginals[(size_t)height] = 1;
+    }
+    for (int y = 0; y < height; y++) t.cdf_rows[(size_t)y * (width + 1) + width] = 1;
+}
+V2 table2d_sample(const OracleScene::Table2D &t, const V2 &rnd) {
+    int w = t.width, h = t.height;
+    const Real *y_ptr = std::upper_bound(t.cdf_marginals.data(), t.cdf_marginals.data() + h + 1, rnd.y);
+    int y_offset = std::min(std::max(int(y_ptr - t.cdf_marginals.data() - 1), 0), h - 1);
+    Real dy = rnd.y - t.cdf_marginals[(size_t)y_offset];
+    if ((t.cdf_marginals[(size_t)y_offset + 1] - t.cdf_marginals[(size_t)y_offset]) > 0) dy /= (t.cdf_marginals[(size_t)y_offset + 1] - t.cdf_marginals[(size_t)y_offset]);
+    const Real *cdf = &t.cdf_rows[(size_t)y_offset * (w + 1)];
+    const Real *x_ptr = std::upper_bound(cdf, cdf + w + 1, rnd.x);
+    int x_offset = std::min(std::max(int(x_ptr - cdf - 1), 0), w - 1);
+    Real dx = rnd.x - cdf[x_offset];
+    if (cdf[x_offset + 1] - cdf[x_offset] > 0) dx /= (cdf[x_offset + 1] - cdf[x_offset]);
+    return V2{(x_offset + dx) / w, (y_offset + dy) / h};
+}
+Real table2d_pdf(const OracleScene::Table2D &t, const V2 &xy) {
+    int w = t.width, h = t.height;
+    int x = (int)std::min(std::max(xy.x * w, Real(0)), Real(w - 1));
+    int y = (int)std::min(std::max(xy.y * h, Real(0)), Real(h - 1));
+    return t.pdf_marginals[(size_t)y] * t.pdf_rows[(size_t)y * w + x] * w * h;
+}
+
+// Envmap, src/lights/envmap.inl
+inline V2 envmap_uv(const V3 &local_dir) {
+    const Real c_INVTWOPI = Real(1) / c_TWOPI, c_INVPI = Real(1) / c_PI;   // src/lajolla.h
+    V2 uv{std::atan2(local_dir.x, -local_dir.z) * c_INVTWOPI, std::acos(std::min(std::max(local_dir.y, Real(-1)), Real(1))) * c_INVPI};
+    if (uv.x < 0) uv.x += 1;
+    return uv;
+}
+V3 envmap_emission(const OracleScene &sc, const V3 &view_dir) {                     // :49-64; view_dir points away from the light
+    const GdptEnvmap &e = sc.desc.envmap;
+    V3 local_dir = xform_vector(e.to_local, -view_dir);
+    V2 uv = envmap_uv(local_dir);
+    V3 w = local_dir;
+    Real dudwx = -w.z / (w.x * w.x + w.z * w.z);
+    Real dudwz = w.x / (w.x * w.x + w.z * w.z);
+    Real dvdwy = -1 / std::sqrt(rmax(1 - w.y * w.y, Real(0)));
+    Real footprint = rmin(std::sqrt(dudwx * dudwx + dudwz * dudwz), dvdwy);
+    GdptTexture t{};
+    t.type = GDPT_TEX_IMAGE; t.image_id = e.image_id; t.uscale = t.vscale = 1; t.uoffset = t.voffset = 0;
+    return tex_eval3(sc, t, uv, footprint) * e.scale;
+}
+V3 envmap_sample_dir(const OracleScene &sc, const V2 &rnd_uv) {                      // :7-18, returns world_dir (normal = -world_dir)
+    V2 uv = table2d_sample(sc.env_table, rnd_uv);
+    Real azimuth = uv.x * (2 * c_PI);
+    Real elevation = uv.y * c_PI;
+    V3 local_dir{std::sin(azimuth) * std::sin(elevation), std::cos(elevation), -std::cos(azimuth) * std::sin(elevation)};
+    return xform_vector(sc.desc.envmap.to_world, local_dir);
+}
+Real envmap_pdf(const OracleScene &sc, const V3 &normal) {                           // :20-37 (point_on_light.normal)
+    V3 world_dir = -normal;
+    V3 local_dir = xform_vector(sc.desc.envmap.to_local, world_dir);
+    V2 uv = envmap_uv(local_dir);
+    Real cos_elevation = local_dir.y;
+    Real sin_elevation = std::sqrt(std::min(std::max(1 - cos_elevation * cos_elevation, Real(0)), Real(1)));
+    if (sin_elevation <= 0) return 0;
+    return table2d_pdf(sc.env_table, uv) / (2 * c_PI * c_PI * sin_elevation);
+}
+
 struct PointNormal { V3 position, normal; };
 
 PointNormal sample_point_on_shape(const OracleScene &sc, int shape_id, const V3 &ref_point, const V2 &uv, Real w) {
@@ -1252,7 +1343,8 @@ V3 path_sample(const OracleScene &sc, int x, int y, Pcg &rng, int *bounces_out, 
     Ray ray = sample_primary(D.camera, screen_pos);
     Real rd_spread = Real(0.25) / Real(std::max(w, h));                              // init_ray_differential, src/ray.h:33-35
     Vertex vertex;
-    if (!intersect(sc, ray, 0, rd_spread, &vertex)) return {0, 0, 0};               // :31-43 (no envmap)
+    if (!intersect(sc, ray, 0, rd_spread, &vertex))                                 // :31-43
+        return D.has_envmap ? envmap_emission(sc, -ray.dir) : V3{0, 0, 0};
     V3 radiance{0, 0, 0};
     V3 throughput{1, 1, 1};
     Real eta_scale = 1;
@@ -1268,10 +1360,11 @@ V3 path_sample(const OracleScene &sc, int x, int y, Pcg &rng, int *bounces_out, 
         Real shape_w = pcg_real(rng);
         int light_id = table_sample(sc.light_pmf, sc.light_cdf, light_w);
         const GdptLight &light = D.lights[light_id];
-        PointNormal pl = sample_point_on_shape(sc, light.shape_id, vertex.position, light_uv, shape_w);
+        const bool env_light = D.has_envmap && light_id == D.envmap.light_id;
         V3 C1{0, 0, 0};
         Real w1 = 0;
-        {
+        if (!env_light) {
+            PointNormal pl = sample_point_on_shape(sc, light.shape_id, vertex.position, light_uv, shape_w);
             Real G = 0;
             V3 dir_light = normalize(pl.position - vertex.position);
             Real dist = std::sqrt(distance_squared(pl.position, vertex.position));
@@ -1284,6 +1377,25 @@ V3 path_sample(const OracleScene &sc, int x, int y, Pcg &rng, int *bounces_out, 
                 V3 dir_view = -ray.dir;
                 V3 f = bsdf_eval(sc, mat, dir_view, dir_light, vertex);
                 V3 L = (dot(pl.normal, -dir_light) <= 0) ? V3{0, 0, 0} : V3{light.intensity[0], light.intensity[1], light.intensity[2]};
+                C1 = G * f * L;
+                Real p2 = bsdf_pdf(sc, mat, dir_view, dir_light, vertex);
+                p2 *= G;
+                w1 = (p1 * p1) / (p1 * p1 + p2 * p2);
+                C1 = C1 / p1;
+            }
+        } else {                                                                    // :151-160: directional, G = 1 if unoccluded
+            V3 world_dir = envmap_sample_dir(sc, light_uv);
+            V3 normal = -world_dir;                                                 // point_on_light.normal
+            V3 dir_light = -normal;
+            Real G = 0;
+            Ray shadow_ray{vertex.position, dir_light, shadow_eps, std::numeric_limits<Real>::infinity()};
+            shadows++; rays++;
+            if (!occluded(sc, shadow_ray)) G = 1;
+            Real p1 = sc.light_pmf[(size_t)light_id] * envmap_pdf(sc, normal);
+            if (G > 0 && p1 > 0) {
+                V3 dir_view = -ray.dir;
+                V3 f = bsdf_eval(sc, mat, dir_view, dir_light, vertex);
+                V3 L = envmap_emission(sc, -dir_light);
                 C1 = G * f * L;
                 Real p2 = bsdf_pdf(sc, mat, dir_view, dir_light, vertex);
                 p2 *= G;
@@ -1315,6 +1427,14 @@ V3 path_sample(const OracleScene &sc, int x, int y, Pcg &rng, int *bounces_out, 
             V3 C2 = G * f * L;
             C2 = C2 / p2;
             radiance = radiance + throughput * C2;
+        }
+        else if (!hit && D.has_envmap) {                                            // :307-325: WITH the MIS weight
+            V3 L = envmap_emission(sc, -dir_bsdf);
+            V3 C2 = G * f * L;
+            Real p1 = sc.light_pmf[(size_t)D.envmap.light_id] * envmap_pdf(sc, -dir_bsdf);
+            Real w2 = (p2 * p2) / (p1 * p1 + p2 * p2);
+            C2 = C2 / p2;
+            radiance = radiance + throughput * C2 * w2;
         }
         if (!hit) break;                                                            // :327-329
         Real rr_prob = 1;
@@ -1370,6 +1490,7 @@ OracleScene *oracle_scene_create(const GdptSceneDesc *desc, int use_bvh) {
     // bounds sphere + epsilon, src/scene.cpp:29-33, src/scene.h:100-102
     V3 l{lb[0], lb[1], lb[2]}, u{ub[0], ub[1], ub[2]};
     Real radius = std::sqrt(distance_squared(u, l)) / 2;
+    sc->bounds_radius = radius;
     sc->isect_eps = rmin(radius * Real(1e-5), Real(0.01));
     for (int i = 0; i < desc->num_images; i++) sc->mips.push_back(make_mip(desc->images[i]));
     if (sc->use_bvh) {
@@ -1400,10 +1521,29 @@ OracleScene *oracle_scene_create(const GdptSceneDesc *desc, int use_bvh) {
         make_table_1d(areas, sc->mesh_tables[(size_t)sidx].pmf, sc->mesh_tables[(size_t)sidx].cdf);
         sc->mesh_tables[(size_t)sidx].total_area = total;
     }
+    if (desc->has_envmap) {                                                // init_sampling_dist, src/lights/envmap.inl:66-83
+        const Mip &m = sc->mips[(size_t)desc->envmap.image_id];
+        int w = m.w[0], h = m.h[0];
+        std::vector<Real> f((size_t)w * h);
+        size_t i = 0;
+        for (int y = 0; y < h; y++) {
+            Real v = (y + Real(0.5)) / Real(h);
+            Real sin_elevation = std::sin(c_PI * v);
+            for (int x = 0; x < w; x++) {
+                Real uu = (x + Real(0.5)) / Real(w);
+                f[i++] = luminance(mip_lookup(m, uu, v, 0)) * sin_elevation;
+            }
+        }
+        make_table_2d(f, w, h, sc->env_table);
+    }
     {
         std::vector<Real> power((size_t)desc->num_lights);
         for (int l = 0; l < desc->num_lights; l++) {                       // light_power, src/lights/diffuse_area_light.inl:1-3
             const GdptLight &lt = desc->lights[l];
+            if (lt.shape_id < 0) {                                         // envmap.inl:1-5
+                power[(size_t)l] = c_PI * sc->bounds_radius * sc->bounds_radius * sc->env_table.total_values / (sc->env_table.width * sc->env_table.height);
+                continue;
+            }
             power[(size_t)l] = luminance(V3{lt.intensity[0], lt.intensity[1], lt.intensity[2]}) * surface_area(*sc, lt.shape_id) * c_PI;
         }
         if (!power.empty()) make_table_1d(power, sc->light_pmf, sc->light_cdf);
@@ -1587,10 +1727,21 @@ void oracle_path_sample(const OracleScene *s, int x, int y, uint64_t *state, uin
     if (shadow_rays) *shadow_rays = sh;
 }
 
+void oracle_table2d(const double *f, int width, int height, const double *rnd, int n_rnd, double *uv_out, double *pdf_out, double *total) {
+    OracleScene::Table2D t;
+    make_table_2d(std::vector<Real>(f, f + (size_t)width * height), width, height, t);
+    *total = t.total_values;
+    for (int i = 0; i < n_rnd; i++) {
+        V2 uv = table2d_sample(t, V2{rnd[2 * i], rnd[2 * i + 1]});
+        uv_out[2 * i] = uv.x; uv_out[2 * i + 1] = uv.y;
+        pdf_out[i] = table2d_pdf(t, uv);
+    }
+}
+
 int oracle_path_render(const OracleScene *s, int spp, int rng_scheme, int row_begin, int row_end, int threads,
                        double *img, OracleStats *stats) {
     const OracleScene &sc = *s;
-    if (sc.desc.has_envmap || sc.desc.num_lights <= 0) return 2;
+    if (sc.desc.num_lights <= 0) return 2;
     int w = sc.desc.camera.width, h = sc.desc.camera.height;
     if (spp <= 0) spp = sc.desc.samples_per_pixel;
     if (row_begin == 0 && row_end == 0) row_end = h;

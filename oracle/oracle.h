@@ -92,7 +92,9 @@ int oracle_occluded(const OracleScene *s, const double org[3], const double dir[
  * drawn x first (the left-to-right order of the compiler the reference was developed with). */
 void oracle_path_sample(const OracleScene *s, int x, int y, uint64_t *state, uint64_t inc, double radiance[3], int32_t *bounces, int32_t *shadow_rays);
 /* path_render tile loop (src/render.cpp:74-117): img = mean over spp of path_tracing. W*H*3 doubles, caller-zeroed.
- * Returns non-zero for scenes with an environment map (not restated). */
+ * Returns non-zero for scenes without any emitter. Environment maps: src/lights/envmap.inl. */
+/* TableDist2D (src/table_dist.cpp:40-150) built over f (row-major, height rows): sample(rnd) -> uv, pdf(uv). */
+void oracle_table2d(const double *f, int width, int height, const double *rnd, int n_rnd, double *uv_out, double *pdf_out, double *total);
 int oracle_path_render(const OracleScene *s, int spp, int rng_scheme, int row_begin, int row_end, int threads,
                        double *img, OracleStats *stats);
 

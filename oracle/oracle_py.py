@@ -83,6 +83,7 @@ def lib():
                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.oracle_path_render.restype = C.c_int
         L.oracle_path_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, C.POINTER(OracleStats)]
+        L.oracle_table2d.argtypes = [dp, C.c_int, C.c_int, dp, C.c_int, dp, dp, dp]
         L.oracle_assemble.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp]
         L.oracle_poisson_dct.argtypes = [C.c_int, C.c_int, dp, dp, dp, C.c_double, dp]
         _LIB = L
@@ -215,6 +216,15 @@ def _path_methods():
 
 
 _path_methods()
+
+
+def table2d(f, rnd):
+    """TableDist2D (src/table_dist.cpp:40-150) over the HxW array f: returns (uv samples for rnd (Nx2), their pdf, total)."""
+    f = np.ascontiguousarray(f, dtype=np.float64)
+    rnd = np.ascontiguousarray(rnd, dtype=np.float64).reshape(-1, 2)
+    uv, pdf, total = np.zeros_like(rnd), np.zeros(len(rnd)), np.zeros(1)
+    lib().oracle_table2d(_dp(f), f.shape[1], f.shape[0], _dp(rnd), len(rnd), _dp(uv), _dp(pdf), _dp(total))
+    return uv, pdf, float(total[0])
 
 
 def pcg_init(stream):

@@ -353,6 +353,26 @@ static void emit_light_sampling(const std::string &scene_dir) {
         for (int i = 0; i < 10; i++) printf("%s[%.17g,%d]", i ? "," : "", us[i], sample(t, us[i]));
         printf("]},");
     }
+    {   // TableDist2D (the environment map's sampling table), incl. a black row and a single bright texel
+        const int w = 6, h = 4;
+        std::vector<Real> f = {0.2, 0.5, 0.0, 1.5, 0.25, 0.75,
+                               0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
+                               3.0, 0.125, 0.5, 0.5, 2.0, 0.0625,
+                               0.0, 0.0, 9.0, 0.0, 0.0, 0.0};
+        TableDist2D t = make_table_dist_2d(f, w, h);
+        printf("\"table2d\":{\"width\":6,\"height\":4,\"f\":[");
+        for (size_t i = 0; i < f.size(); i++) printf("%s%.17g", i ? "," : "", f[i]);
+        printf("],\"total\":%.17g,\"samples\":[", t.total_values);
+        for (int i = 0; i < 40; i++) {
+            Vector2 r{urand(), urand()};
+            if (i == 0) r = Vector2{0.0, 0.0};
+            if (i == 1) r = Vector2{0.999999999, 0.999999999};
+            if (i == 2) r = Vector2{0.5, 0.2};
+            Vector2 uv = sample(t, r);
+            printf("%s{\"rnd\":[%.17g,%.17g],\"uv\":[%.17g,%.17g],\"pdf\":%.17g}", i ? "," : "", r.x, r.y, uv.x, uv.y, pdf(t, uv));
+        }
+        printf("]},");
+    }
     printf("\"meshes\":[");
     for (int m = 0; m < 2; m++) {
         Matrix4x4 to_world = (m == 0) ? translate(Vector3{0.0, (double)-0.5f, 0.0}) : rotate(30.0, Vector3{0.2, 1.0, 0.1}) * scale(Vector3{1.5, 1.0, 0.5});
