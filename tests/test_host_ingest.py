@@ -74,6 +74,8 @@ def test_scene_defaults_and_quirks(G, tmp_path):
     assert (d.camera.width, d.camera.height, d.integrator, d.samples_per_pixel) == (256, 256, G.INTEGRATOR_PATH, 4)
     assert d.camera.filter_type == G.FILTER_BOX and d.output_filename == b"image.exr"
     # $defaults, stof truncation ("1e5+1" -> 1e5), single-valued spectrum reflectance -> (1,1,1), sphere ignores toWorld
+    import numpy as np
+    G.imwrite(str(tmp_path / "env.pfm"), np.full((2, 4, 3), 0.5))
     p = tmp_path / "q.xml"
     p.write_text("""<scene version="0.5.0"><default name="res" value="48"/><default name="s" value="7"/>
       <integrator type="gradpath"><integer name="maxDepth" value="3"/><integer name="rrDepth" value="2"/></integrator>
@@ -85,16 +87,24 @@ def test_scene_defaults_and_quirks(G, tmp_path):
         <transform name="toWorld"><translate x="100"/></transform>
         <bsdf type="diffuse"><spectrum name="reflectance" value="0.3"/></bsdf>
         <emitter type="area"><rgb name="radiance" value="1 2 3"/></emitter></shape>
-      <emitter type="envmap"><string name="filename" value="nowhere.exr"/></emitter>
+      <emitter type="envmap"><string name="filename" value="env.pfm"/><float name="scale" value="2.5"/></emitter>
     </scene>""")
     sd = G.parse_scene(str(p))
     d = sd.desc
+    # the environment map is a light in parse order (src/parsers/parse_scene.cpp:1484-1508): placeholder + GdptEnvmap
+    assert d.has_envmap == 1 and d.num_lights == 2 and d.lights[1].shape_id == -1
+    assert d.envmap.light_id == 1 and d.envmap.scale == 2.5 and d.images[d.envmap.image_id].width == 4
+    assert list(d.envmap.to_world) == list(d.envmap.to_local) == [1.0 if i % 5 == 0 else 0.0 for i in range(16)]
+    missing = tmp_path / "m.xml"
+    missing.write_text(p.read_text().replace("env.pfm", "nowhere.exr"))
+    with pytest.raises(G.GdptError, match="Failure when loading image"):
+        G.parse_scene(str(missing))
     assert (d.camera.width, d.camera.height, d.samples_per_pixel, d.max_depth, d.rr_depth) == (48, 32, 7, 3, 2)
     assert d.camera.filter_type == G.FILTER_TENT and d.camera.filter_param == 2.0 and d.output_filename == b"o.pfm"
     s = d.shapes[0]
     assert s.type == G.SHAPE_SPHERE and list(s.center) == [100000.0, 2.0, 3.0] and s.radius == 0.5
     assert list(d.materials[s.material_id].tex[0].v0) == [1.0, 1.0, 1.0]
-    assert list(d.lights[0].intensity) == [1.0, 2.0, 3.0] and d.num_lights == 1   # envmap ignored by GradPath
+    assert list(d.lights[0].intensity) == [1.0, 2.0, 3.0] and d.num_lights == 2   # area light + the envmap placeholder
 
 
 @pytest.mark.parametrize("body,msg", [
