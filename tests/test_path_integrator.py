@@ -240,3 +240,16 @@ def test_gpu_reference_test_scenes(G, O, scene_tmp, rel, filt):
     for k in ("img", "cx0", "cy0", "cx1", "cy1"):
         assert rel_l2(gb[k], ob[k]) < 1e-7, k
     assert gst.bounces == gost.bounces
+
+
+@pytest.mark.gpu
+def test_gpu_matpreview_scene(G, O, scene_tmp):
+    """scenes/matpreview/matpreview.xml as shipped by the reference: Mitsuba .serialized meshes (61 600 triangles), a
+    RoughDielectric material ball, checkerboard floor, lit by the PIZ-compressed environment map only."""
+    xml = scene_variant(scene_tmp, "matpreview/matpreview.xml", width=64, height=64)
+    sd = G.parse_scene(xml)
+    assert sd.desc.integrator == G.INTEGRATOR_PATH and sd.desc.has_envmap == 1
+    sc = G.Scene(sd)
+    got, st = sc.path_render(4, G.RNG_SAMPLE)
+    want, ost = O.OracleScene(sd.ptr, use_bvh=True).path_render(4, G.RNG_SAMPLE, threads=8)
+    assert want.mean() > 0.1 and rel_l2(got, want) < 1e-6 and st.bounces == ost.bounces

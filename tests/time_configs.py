@@ -21,7 +21,8 @@ for name, rel, w, h, integ, spp in cases:
           f"bounces/sample {rs.bounces / rs.samples:.2f}, nonfinite {rs.nonfinite_samples}, poisson {ps.solve_ms:.3f} ms", flush=True)
 # Integrator::Path
 for name, rel, w, h, spp in (("P cbox path 512x512 64spp", "cbox/cbox_gdpt.xml", 512, 512, 64), ("P sponza path 1280x720 16spp", "sponza/sponza.xml", 1280, 720, 16),
-                               ("P veach_mi direct 768x512 64spp", "veach_mi/mi.xml", 768, 512, 64)):
+                               ("P veach_mi direct 768x512 64spp", "veach_mi/mi.xml", 768, 512, 64),
+                               ("P matpreview (envmap, roughdielectric) 512x512 32spp", "matpreview/matpreview.xml", 512, 512, 32)):
     xml = scene_variant(tmp, rel, width=w, height=h, integrator="path")
     sc = G.Scene(G.parse_scene(xml))
     img, st = sc.path_render(spp, G.RNG_SAMPLE)
