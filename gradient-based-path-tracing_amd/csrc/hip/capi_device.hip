@@ -44,6 +44,7 @@ struct GdptScene {
     bool has_envmap = false;
     int scene_spp = 0;             // <sampler sampleCount> of the description (default spp)
     bool one_sided = true, lambert_only = true;
+    bool has_rough = false;        // RoughPlastic / RoughDielectric present: GradPath uses the evaluator built with those lobes
     std::vector<void *> allocations;
     // cached output/work buffers for the host-pointer entry points
     double *d_buf[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -315,6 +316,7 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     for (auto &m : materials) for (auto &t : m.tex) if (t.type != GDPT_TEX_CONSTANT) v.all_textures_constant = 0;
     for (auto &m : materials) {
         if (m.type != GDPT_MAT_LAMBERTIAN) sc->lambert_only = false;
+        if (m.type == GDPT_MAT_ROUGHPLASTIC || m.type == GDPT_MAT_ROUGHDIELECTRIC) sc->has_rough = true;
         if (m.type == GDPT_MAT_DISNEY_GLASS || m.type == GDPT_MAT_DISNEY_BSDF || m.type == GDPT_MAT_ROUGHDIELECTRIC) sc->one_sided = false;   // two-sided lobes
     }
     // get_intersection_epsilon (src/scene.h:100-102) from Embree-style fp32 scene bounds (src/scene.cpp:29-33)
@@ -430,7 +432,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.img = img; rl.cx0 = cx0; rl.cy0 = cy0; rl.cx1 = cx1; rl.cy1 = cy1;
     rl.counters = sc->d_counters;
     rl.count_traversal = stats && stats->nodes_visited == ~0ull;   // request flag: caller presets nodes_visited = UINT64_MAX
-    rl.one_sided_materials = sc->one_sided; rl.lambert_only = sc->lambert_only;
+    rl.one_sided_materials = sc->one_sided && !sc->has_rough; rl.lambert_only = sc->lambert_only;
     rl.scene_fits_lds = gdpt::scene_fits_lds(sc->view.num_nodes, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->bvh_depth);
     auto env_int = [](const char *name, int def) { const char *v = std::getenv(name); return v ? std::atoi(v) : def; };
     rl.force_eager = env_int("GDPT_FORCE_EAGER", 0) != 0;           // tuning / A-B knobs (undocumented defaults are the product path)

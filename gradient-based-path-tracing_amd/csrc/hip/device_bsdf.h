@@ -489,11 +489,15 @@ GD bool rd_sample(const Ctx &c, const GdptMaterial &m, D3 in, D2 ruv, double rw,
 }
 
 // ---- dispatch (std::visit in the reference, src/material.cpp:90-119) -------------------------------
+// ROUGH = false drops the RoughPlastic / RoughDielectric cases: inlined into the switch they cost scenes that never take
+// them 20 % (Disney test scenes in the GradPath lane machine), so that kernel is built without them and scenes that do
+// use them go to the kernels built with ROUGH = true.
+template <bool ROUGH = true>
 GD D3 bsdf_eval(const DevSceneView &sv, const GdptMaterial &m, D3 in, D3 out, const Vertex &v) {
     Ctx c{sv, v};
     switch (m.type) {
-        case GDPT_MAT_ROUGHPLASTIC: return rp_eval(c, m, in, out);
-        case GDPT_MAT_ROUGHDIELECTRIC: return rd_eval(c, m, in, out);
+        case GDPT_MAT_ROUGHPLASTIC: if (ROUGH) return rp_eval(c, m, in, out); else return splat(0);
+        case GDPT_MAT_ROUGHDIELECTRIC: if (ROUGH) return rd_eval(c, m, in, out); else return splat(0);
         case GDPT_MAT_LAMBERTIAN: return lambert_eval(c, m.tex[0], in, out);
         case GDPT_MAT_DISNEY_DIFFUSE: return dd_eval(c, m.tex[0], m.tex[1], m.tex[2], in, out);
         case GDPT_MAT_DISNEY_METAL: return dm_eval(c, T3(c, m.tex[0]), m.tex[1], m.tex[2], in, out);
@@ -504,11 +508,12 @@ GD D3 bsdf_eval(const DevSceneView &sv, const GdptMaterial &m, D3 in, D3 out, co
         default: return splat(0);
     }
 }
+template <bool ROUGH = true>
 GD double bsdf_pdf(const DevSceneView &sv, const GdptMaterial &m, D3 in, D3 out, const Vertex &v) {
     Ctx c{sv, v};
     switch (m.type) {
-        case GDPT_MAT_ROUGHPLASTIC: return rp_pdf(c, m, in, out);
-        case GDPT_MAT_ROUGHDIELECTRIC: return rd_pdf(c, m, in, out);
+        case GDPT_MAT_ROUGHPLASTIC: if (ROUGH) return rp_pdf(c, m, in, out); else return 0;
+        case GDPT_MAT_ROUGHDIELECTRIC: if (ROUGH) return rd_pdf(c, m, in, out); else return 0;
         case GDPT_MAT_LAMBERTIAN: case GDPT_MAT_DISNEY_DIFFUSE: case GDPT_MAT_DISNEY_SHEEN: return cos_pdf(c, in, out);
         case GDPT_MAT_DISNEY_METAL: return dm_pdf(c, m.tex[1], m.tex[2], in, out);
         case GDPT_MAT_DISNEY_GLASS: return dg_pdf(c, m.tex[1], m.tex[2], m.eta, in, out);
@@ -517,11 +522,12 @@ GD double bsdf_pdf(const DevSceneView &sv, const GdptMaterial &m, D3 in, D3 out,
         default: return 0;
     }
 }
+template <bool ROUGH = true>
 GD bool bsdf_sample(const DevSceneView &sv, const GdptMaterial &m, D3 in, const Vertex &v, D2 ruv, double rw, BsdfSample &s) {
     Ctx c{sv, v};
     switch (m.type) {
-        case GDPT_MAT_ROUGHPLASTIC: return rp_sample(c, m, in, ruv, rw, s);
-        case GDPT_MAT_ROUGHDIELECTRIC: return rd_sample(c, m, in, ruv, rw, s);
+        case GDPT_MAT_ROUGHPLASTIC: if (ROUGH) return rp_sample(c, m, in, ruv, rw, s); else return false;
+        case GDPT_MAT_ROUGHDIELECTRIC: if (ROUGH) return rd_sample(c, m, in, ruv, rw, s); else return false;
         case GDPT_MAT_LAMBERTIAN: case GDPT_MAT_DISNEY_SHEEN: return cos_sample(c, in, ruv, 1.0, s);
         case GDPT_MAT_DISNEY_DIFFUSE: return dd_sample(c, m.tex[1], in, ruv, s);
         case GDPT_MAT_DISNEY_METAL: return dm_sample(c, m.tex[1], m.tex[2], in, ruv, s);

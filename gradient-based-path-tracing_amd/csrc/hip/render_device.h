@@ -285,13 +285,16 @@ GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, flo
     tv.cur = cur; tv.sp = sp; tv.best = best;
 }
 
+constexpr int kEagerSearchFrac = 112;     // /256 of the live lanes still searching a leaf when the node loop is left
+
 // One ray, start to finish (eager evaluator).
 template <class TC>
 GD bool intersect_ctx(const DevSceneView &sv, const TraceCtx &tx, const Ray &ray, double rd_spread, Vertex &v, LaneCounters &lc, TraceCounters &tc) {
     lc.rays++;
     Trav tv;
     trav_init(sv, tv, ray.tfar);
-    if (tv.cur != kTravDone) trav_run<TC>(sv, tx, ray.org, ray.dir, (float)ray.tnear, (float)ray.tfar, tv, 0, 0, tc);
+    // run to completion, but leave the inner-node loop early like the lane machine does (kEagerSearchFrac)
+    if (tv.cur != kTravDone) trav_run<TC>(sv, tx, ray.org, ray.dir, (float)ray.tnear, (float)ray.tfar, tv, 0, kEagerSearchFrac, tc);
     if (tv.best.gid < 0) return false;
     make_vertex(sv, tx.tris, tx.need_uv, ray, tv.best, 0.0, rd_spread, v);
     return true;
@@ -303,20 +306,20 @@ GD bool occluded_ctx(const DevSceneView &sv, const TraceCtx &tx, const Ray &ray,
     lc.rays++;
     Trav tv;
     trav_init(sv, tv, ray.tfar);
-    if (tv.cur != kTravDone) trav_run<TC>(sv, tx, ray.org, ray.dir, (float)ray.tnear, (float)ray.tfar, tv, 0, 0, tc, true);
+    if (tv.cur != kTravDone) trav_run<TC>(sv, tx, ray.org, ray.dir, (float)ray.tnear, (float)ray.tfar, tv, 0, kEagerSearchFrac, tc, true);
     return tv.best.gid >= 0;
 }
 
 // ------------------------------------------------------------------------------------------------
 // material dispatch: Lambertian-only scenes get the three-line lobe inline, others the full switch
 // ------------------------------------------------------------------------------------------------
-template <bool LAMBERT>
+template <bool LAMBERT, bool ROUGH = false>
 GD bool mat_sample(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D2 ruv, double rw, BsdfSample &s) {
     if (LAMBERT) { Ctx c{sv, v}; return cos_sample(c, in, ruv, 1.0, s); }
-    return bsdf_sample(sv, tx.materials[v.material_id], in, v, ruv, rw, s);
+    return bsdf_sample<ROUGH>(sv, tx.materials[v.material_id], in, v, ruv, rw, s);
 }
 // eval (f*|cos|) and solid-angle pdf together
-template <bool LAMBERT>
+template <bool LAMBERT, bool ROUGH = false>
 GD void mat_eval_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D3 out, D3 &f, double &pdf) {
     if (LAMBERT) {
         // src/materials/lambertian.inl:1-33 — eval and pdf share the clamped cosine
@@ -328,8 +331,8 @@ GD void mat_eval_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v
         return;
     }
     const GdptMaterial &m = tx.materials[v.material_id];
-    f = bsdf_eval(sv, m, in, out, v);
-    pdf = bsdf_pdf(sv, m, in, out, v);
+    f = bsdf_eval<ROUGH>(sv, m, in, out, v);
+    pdf = bsdf_pdf<ROUGH>(sv, m, in, out, v);
 }
 template <bool LAMBERT>
 GD double mat_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D3 out) {
