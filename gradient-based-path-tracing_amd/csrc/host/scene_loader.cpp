@@ -915,6 +915,8 @@ HostMesh load_serialized(const std::string &filename, int shape_index, const M4 
         uint32_t count;
         std::memcpy(&count, &file[file.size() - 4], 4);
         if ((uint32_t)shape_index >= count) fail("serialized: shape index out of range");
+        const size_t entry = (version == 4) ? 8 : 4;
+        if ((size_t)count > (file.size() - 4) / entry) fail("serialized: corrupt shape table in " + filename);
         size_t sub = 0;
         if (version == 4) {
             uint64_t o;
@@ -925,6 +927,7 @@ HostMesh load_serialized(const std::string &filename, int shape_index, const M4 
             std::memcpy(&o, &file[file.size() - 4 * (size_t)(count - shape_index + 1)], 4);
             sub = o;
         }
+        if (sub >= file.size() - 4) fail("serialized: bad offset");
         offset = sub + 4;
     }
     if (offset >= file.size()) fail("serialized: bad offset");
@@ -952,6 +955,9 @@ HostMesh load_serialized(const std::string &filename, int shape_index, const M4 
     if (version == 4) { char c; do { rd(&c, 1); } while (c != '\0'); }
     uint64_t nv, nt; rd(&nv, 8); rd(&nt, 8);
     bool dbl = flags & 0x2000;
+    // every vertex carries at least a position, every triangle three 32-bit indices: counts beyond what the inflated
+    // stream can hold are corrupt (and must not reach the allocations below)
+    if (nv > out.size() / (dbl ? 24 : 12) || nt > out.size() / 12) fail("serialized: corrupt vertex / triangle count in " + filename);
     auto rdreal = [&]() { if (dbl) { double v; rd(&v, 8); return v; } float v; rd(&v, 4); return (double)v; };
     HostMesh mesh;
     mesh.positions.resize(nv * 3);
