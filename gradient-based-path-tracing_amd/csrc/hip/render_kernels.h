@@ -36,7 +36,7 @@ bool scene_fits_lds_wide(int num_nodes4, int num_prims, int num_tris, int num_ma
 
 // Doubles the `partials` buffer must hold for a band of `pixels` pixels at `spp`.
 void launch_path_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t stream);
-int render_log2_chunks(int spp, int force_log2k);
+int render_log2_chunks(int spp, int force_log2k, long long pixels);
 size_t render_partials_doubles(int width, int rows, int spp, int force_log2k);
 
 // Enqueues the five-buffer render on `stream`. Throws std::runtime_error on a launch failure.

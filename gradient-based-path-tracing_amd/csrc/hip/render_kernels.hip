@@ -44,7 +44,7 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
             launch_eager(sv, a, dim3((unsigned)(a.tiles_x * tiles_y)), stream);
         } else {
             // persistent lanes pulling (pixel, chunk) items: >= 4 samples per item, at most 8 items per pixel
-            a.log2c = render_log2_chunks(rl.spp, rl.force_log2k);
+            a.log2c = render_log2_chunks(rl.spp, rl.force_log2k, (long long)W * rows);
             a.tiles_x = (W + 15) / 16;
             const long long tiles = (long long)a.tiles_x * ((rows + 15) / 16);
             a.num_items = (tiles * 256) << a.log2c;
@@ -84,7 +84,7 @@ void launch_path_render(const DevSceneView &sv, const RenderLaunch &rl, hipStrea
         // persistent lanes pulling (pixel, chunk) items, as the GradPath kernel does
         a.thresh_a = rl.thresh_a >= 0 ? (rl.thresh_a > 255 ? 255 : rl.thresh_a) : 64;
         a.thresh_c = rl.thresh_c >= 0 ? (rl.thresh_c > 255 ? 255 : rl.thresh_c) : 112;
-        a.log2c = render_log2_chunks(rl.spp, rl.force_log2k);
+        a.log2c = render_log2_chunks(rl.spp, rl.force_log2k, (long long)W * rows);
         a.tiles_x = (W + 15) / 16;
         const long long tiles = (long long)a.tiles_x * ((rows + 15) / 16);
         a.num_items = (tiles * 256) << a.log2c;
@@ -118,16 +118,22 @@ void launch_path_render(const DevSceneView &sv, const RenderLaunch &rl, hipStrea
     if (e != hipSuccess) throw std::runtime_error(std::string("path kernel launch failed: ") + hipGetErrorString(e));
 }
 
-int render_log2_chunks(int spp, int force_log2k) {
-    int log2c = 0;
-    while (log2c < 3 && (8 << log2c) <= spp) log2c++;          // 2^log2c <= spp/4, at most 8
+// Work items per pixel = 2^log2c chunks of its sample range: at least 4 samples per item, at most 8 items per pixel on
+// large films; small bands with many samples (multi-GPU row bands) are cut finer, towards ~2^20 items per launch, so
+// that every lane still sees several items and the drain at the end of the kernel stays one short item long.
+int render_log2_chunks(int spp, int force_log2k, long long pixels) {
+    int by_spp = 0;
+    while ((8 << by_spp) <= spp) by_spp++;                      // 2^by_spp <= spp / 4
+    int target = 0;
+    while (target < 8 && (pixels << target) < (1LL << 20)) target++;
+    int log2c = by_spp < (target > 3 ? target : 3) ? by_spp : (target > 3 ? target : 3);
     if (force_log2k >= 0) { log2c = force_log2k; while (log2c > 0 && (1 << log2c) > spp) log2c--; }
     return log2c;
 }
 
 size_t render_partials_doubles(int width, int rows, int spp, int force_log2k) {
     const long long tiles = (long long)((width + 15) / 16) * ((rows + 15) / 16);
-    return (size_t)16 * (size_t)((tiles * 256) << render_log2_chunks(spp, force_log2k));
+    return (size_t)16 * (size_t)((tiles * 256) << render_log2_chunks(spp, force_log2k, (long long)width * rows));
 }
 
 bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_materials, int bvh_depth) {
