@@ -927,7 +927,7 @@ GD void accumulate_eager(AccReg &a, const SampleOut &s, double spp, LaneCounters
     for (int k = 0; k < 4; k++) acc_offset(a, k, s.contrib, s.cX[k], s.w[k], s.prob, spp, lc, flagged);
 }
 
-__global__ __launch_bounds__(kBlock) void gdpt_render_eager(DevSceneView sv, KernelArgs a) {
+__global__ __launch_bounds__(kBlock, 2) void gdpt_render_eager(DevSceneView sv, KernelArgs a) {
     __shared__ int s_stack[GDPT_BVH_MAX_DEPTH * kBlock];
     const int tid = threadIdx.x;
     TraceCtx tx = setup_trace<false, true>(sv, nullptr, s_stack, tid, kBlock, a.count != 0);

@@ -266,7 +266,7 @@ GD void path_count_nonfinite(D3 r, LaneCounters &lc) { if (!isfinite(r.x + r.y +
 #ifdef GDPT_BUILD_PATH_MISC   // non-template kernels: emitted by render_path.hip only
 // SAMPLE streams: K = 2^log2k lanes per pixel, each sums a contiguous chunk of the pixel's samples; the K partial sums
 // are combined in a fixed-order tree and divided by spp (src/render.cpp:107-110).
-__global__ __launch_bounds__(kBlock) void gdpt_path_eager(DevSceneView sv, KernelArgs a) {
+__global__ __launch_bounds__(kBlock, 2) void gdpt_path_eager(DevSceneView sv, KernelArgs a) {
     __shared__ int s_stack[GDPT_BVH_MAX_DEPTH * kBlock];
     const int tid = threadIdx.x;
     TraceCtx tx = setup_trace<false, true>(sv, nullptr, s_stack, tid, kBlock, a.count != 0);
