@@ -51,6 +51,7 @@ struct GdptScene {
     size_t buf_elems = 0;
     gdpt::RenderCounters *d_counters = nullptr;
     gdpt::RenderCounters *h_counters = nullptr; // pinned
+    void *d_bounce_log = nullptr; size_t bounce_log_bytes = 0;   // per-lane bounce log of the two-sided lane machine
     double *d_partials = nullptr; size_t partials_doubles = 0;   // work-item partial sums of the persistent render kernel
     unsigned long long *d_queue = nullptr;
     int num_cus = 256;
@@ -71,6 +72,7 @@ struct GdptScene {
         for (auto &b : d_buf) if (b) hipFree(b);
         if (d_counters) hipFree(d_counters);
         if (d_partials) hipFree(d_partials);
+        if (d_bounce_log) hipFree(d_bounce_log);
         if (d_queue) hipFree(d_queue);
         if (h_counters) hipHostFree(h_counters);
         if (ev0) hipEventDestroy(ev0);
@@ -450,6 +452,19 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
         rl.partials = sc->d_partials; rl.queue_head = sc->d_queue;
     }
     if (env_int("GDPT_NO_LDS_SCENE", 0)) rl.scene_fits_lds = false;
+    // two-sided lobes (DisneyGlass, DisneyBSDF) without rough ones: lane machine with offsets replayed from a bounce log
+    rl.two_sided_machine = !sc->one_sided && !sc->has_rough && !rl.force_eager && b.rng == GDPT_RNG_SAMPLE && !env_int("GDPT_NO_TWOSIDED_MACHINE", 0);
+    if (rl.two_sided_machine) {
+        const long long tiles = (long long)((sc->view.cam.width + 15) / 16) * ((b.row_end - b.row_begin + 15) / 16);
+        const long long items = (tiles * 256) << gdpt::render_log2_chunks(b.spp, rl.force_log2k, (long long)sc->view.cam.width * (b.row_end - b.row_begin));
+        const size_t need = gdpt::twosided_log_bytes(gdpt::persistent_blocks(rl, items));
+        if (need > sc->bounce_log_bytes) {
+            if (sc->d_bounce_log) { ck(hipStreamSynchronize(stream), "hipStreamSynchronize"); hipFree(sc->d_bounce_log); sc->d_bounce_log = nullptr; }
+            ck(hipMalloc(&sc->d_bounce_log, need), "hipMalloc(bounce log)");
+            sc->bounce_log_bytes = need;
+        }
+        rl.bounce_log = sc->d_bounce_log; rl.bounce_log_bytes = sc->bounce_log_bytes;
+    }
     rl.lds_wide = rl.scene_fits_lds && env_int("GDPT_LDS_WIDE", 1) != 0 &&
                   gdpt::scene_fits_lds_wide(sc->view.num_nodes4, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->wide_stack_need);
     ck(hipMemsetAsync(sc->d_counters, 0, sizeof(gdpt::RenderCounters), stream), "hipMemsetAsync(counters)");

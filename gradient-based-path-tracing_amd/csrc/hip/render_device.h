@@ -994,6 +994,7 @@ namespace gdpt {
 void launch_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lds_wide, hipStream_t stream);
 void launch_reduce_partials(const DevSceneView &sv, const gd::KernelArgs &a, hipStream_t stream);
 void launch_phases_general(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lds_wide, hipStream_t stream);
+void launch_phases_twosided(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, void *bounce_log, hipStream_t stream);
 void launch_tile_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
 void launch_tile_phases_general(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
 void launch_eager(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, hipStream_t stream);

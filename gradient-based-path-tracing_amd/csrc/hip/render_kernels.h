@@ -26,6 +26,9 @@ struct RenderLaunch {
     int thresh_a, thresh_c;        // trace-phase exit fractions /256 (unfinished rays; lanes still searching a leaf), -1 = default
     int force_log2k;               // lanes per pixel = 2^force_log2k (-1 = automatic)
     bool lds_wide;                 // LDS-resident scene walked in its BVH4 form
+    bool two_sided_machine;        // two-sided lobes present (and no rough ones): lane machine with replayed offsets
+    void *bounce_log;              // its per-lane log (device), sized by twosided_log_bytes(blocks)
+    size_t bounce_log_bytes;
     int num_cus;                   // compute units of the device (persistent grid size)
     int blocks_per_cu;             // persistent blocks per CU (0 = default 2)
     double *partials;              // device, >= 15 * W * rows * 8 doubles (work-item partial sums)
@@ -35,6 +38,8 @@ bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_material
 bool scene_fits_lds_wide(int num_nodes4, int num_prims, int num_tris, int num_materials, int wide_stack_need);
 
 // Doubles the `partials` buffer must hold for a band of `pixels` pixels at `spp`.
+size_t twosided_log_bytes(unsigned blocks);
+unsigned persistent_blocks(const RenderLaunch &rl, long long num_items);
 void launch_path_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t stream);
 int render_log2_chunks(int spp, int force_log2k, long long pixels);
 size_t render_partials_doubles(int width, int rows, int spp, int force_log2k);

@@ -21,7 +21,7 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
     a.count = rl.count_traversal ? 1 : 0;
     const int W = sv.cam.width, rows = rl.row_end - rl.row_begin;
     if (W <= 0 || rows <= 0 || rl.spp <= 0) throw std::runtime_error("launch_render: empty image band or spp <= 0");
-    const bool phases = rl.one_sided_materials && !rl.force_eager;
+    const bool phases = (rl.one_sided_materials || rl.two_sided_machine) && !rl.force_eager;
     if (rl.rng_scheme == GDPT_RNG_TILE) {
         int ntx = (W + 15) / 16, nty = (sv.cam.height + 15) / 16;
         dim3 grid((unsigned)((ntx * nty + 63) / 64));
@@ -53,12 +53,12 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
             if (!a.partials || !a.queue_head) throw std::runtime_error("launch_render: work-queue buffers missing");
             hipError_t me = hipMemsetAsync(a.queue_head, 0, sizeof(unsigned long long), stream);
             if (me != hipSuccess) throw std::runtime_error("launch_render: queue reset failed");
-            long long waves_needed = (a.num_items + 63) / 64;
-            long long blocks = (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2);   // 2 resident blocks per CU (LDS-bound); surplus blocks just queue
-            if (blocks > (waves_needed + 3) / 4) blocks = (waves_needed + 3) / 4;
-            if (blocks < 1) blocks = 1;
-            dim3 grid((unsigned)blocks);
-            if (rl.lambert_only) launch_phases_lambert(sv, a, grid, rl.scene_fits_lds, rl.lds_wide, stream);
+            const unsigned blocks = persistent_blocks(rl, a.num_items);   // 2 resident blocks per CU (LDS-bound)
+            dim3 grid(blocks);
+            if (rl.two_sided_machine) {
+                if (!rl.bounce_log || rl.bounce_log_bytes < twosided_log_bytes(blocks)) throw std::runtime_error("launch_render: bounce log missing");
+                launch_phases_twosided(sv, a, grid, rl.scene_fits_lds && rl.lds_wide, rl.bounce_log, stream);
+            } else if (rl.lambert_only) launch_phases_lambert(sv, a, grid, rl.scene_fits_lds, rl.lds_wide, stream);
             else launch_phases_general(sv, a, grid, rl.scene_fits_lds, rl.lds_wide, stream);
             launch_reduce_partials(sv, a, stream);
         }
@@ -121,6 +121,13 @@ void launch_path_render(const DevSceneView &sv, const RenderLaunch &rl, hipStrea
 // Work items per pixel = 2^log2c chunks of its sample range: at least 4 samples per item, at most 8 items per pixel on
 // large films; small bands with many samples (multi-GPU row bands) are cut finer, towards ~2^20 items per launch, so
 // that every lane still sees several items and the drain at the end of the kernel stays one short item long.
+unsigned persistent_blocks(const RenderLaunch &rl, long long num_items) {
+    long long waves_needed = (num_items + 63) / 64;
+    long long blocks = (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2);
+    if (blocks > (waves_needed + 3) / 4) blocks = (waves_needed + 3) / 4;
+    return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
 int render_log2_chunks(int spp, int force_log2k, long long pixels) {
     int by_spp = 0;
     while ((8 << by_spp) <= spp) by_spp++;                      // 2^by_spp <= spp / 4

@@ -245,3 +245,24 @@ def test_roughplastic_and_roughdielectric_boxes(G, O, scene_tmp):
         img, pst = sc.path_render(4, G.RNG_SAMPLE)
         pwant, post = O.OracleScene(sd.ptr).path_render(4, G.RNG_SAMPLE, threads=8)
         assert rel_l2(img, pwant) < tol and pst.bounces == post.bounces
+
+
+@pytest.mark.parametrize("scene", ["disney_glass.xml", "disney_bsdf.xml"])
+def test_two_sided_lane_machine_replays_offsets_exactly(G, O, scene_tmp, scene, monkeypatch):
+    """Two-sided lobes: the lane machine logs the base path's (material, p2) per bounce and replays the four offsets from
+    the log (render_twosided.h); the straight-loop evaluator carries them along. Same arithmetic, two schedules — and
+    both equal the oracle, rays and bounces included."""
+    xml = scene_variant(scene_tmp, "disney_bsdf_test/" + scene, width=64, height=48, integrator="gradpath")
+    sd = G.parse_scene(xml)
+    sc = G.Scene(sd)
+    got, st = sc.render(6, G.RNG_SAMPLE)
+    monkeypatch.setenv("GDPT_NO_TWOSIDED_MACHINE", "1")
+    eager, est = sc.render(6, G.RNG_SAMPLE)
+    monkeypatch.delenv("GDPT_NO_TWOSIDED_MACHINE")
+    want, ost = O.OracleScene(sd.ptr, use_bvh=True).render(6, G.RNG_SAMPLE, threads=8)
+    for k in BUFS:
+        assert rel_l2(got[k], eager[k]) < 1e-12, k
+    check_buffers(got, want, 1e-7)
+    # (samples whose BSDF sampling fails return the zero record: the lane machine never traces their offset rays)
+    assert st.bounces == est.bounces == ost.bounces and st.rays <= est.rays
+    assert np.abs(want["cx0"]).max() > 0

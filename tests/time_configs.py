@@ -11,7 +11,7 @@ cases = [("C2 cbox 512x512 16spp", "cbox/cbox_gdpt.xml", 512, 512, None, 16),
          ("C4 sponza 1280x720 64spp", "sponza/sponza.xml", 1280, 720, None, 64),
          ("C5 disney_diffuse 512x512 64spp", "disney_bsdf_test/disney_diffuse.xml", 512, 512, "gradpath", 64),
          ("C5 disney_metal 512x512 64spp", "disney_bsdf_test/disney_metal.xml", 512, 512, "gradpath", 64),
-         ("C5 disney_bsdf 512x512 64spp (eager)", "disney_bsdf_test/disney_bsdf.xml", 512, 512, "gradpath", 64)]
+         ("C5 disney_bsdf 512x512 64spp (two-sided lane machine)", "disney_bsdf_test/disney_bsdf.xml", 512, 512, "gradpath", 64)]
 for name, rel, w, h, integ, spp in cases:
     xml = scene_variant(tmp, rel, width=w, height=h, integrator=integ)
     sc = G.Scene(G.parse_scene(xml))
