@@ -109,7 +109,11 @@ def gen_images():
     # the reference's own renders (fp16 + ZIP EXR written by lajolla): coarse statistics for end-to-end sanity checks
     doc["reference_renders"] = {}
     for rel in ("cbox_gdpt/cb_16.exr", "cbox_gdpt/cb_4.exr", "cbox_gdpt/cb_1.exr", "gdpt_renders/tmp_gdpt_0.04.exr",
-                "cbox_path/cb_1000.exr", "cbox_path/cb_256.exr", "cbox_path/cb_16.exr"):
+                "cbox_path/cb_1000.exr", "cbox_path/cb_256.exr", "cbox_path/cb_16.exr",
+                "extra_images/disney_glass_eta_1.5.exr", "extra_images/disney_sheen_test_1.0.exr",
+                "gdpt_renders/sponza_grad_path_trace/s_gp_256.exr", "gdpt_renders/sponza_grad_path_trace/s_gp_16.exr",
+                "gdpt_renders/sponza_regular_path_trace/sp_256.exr", "gdpt_renders/sponza_reg_path_non_nee/sp_256.exr",
+                "gdpt_renders/sponza.exr"):
         path = os.path.join(REF, rel)
         if not os.path.exists(path):
             continue

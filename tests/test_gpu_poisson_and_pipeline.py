@@ -157,3 +157,20 @@ def test_pipeline_output_agrees_with_the_reference_own_render(G):
     thumb = out.reshape(h // bs, bs, w // bs, bs, 3).mean(axis=(1, 3))
     ref = np.array(gold["block_mean_32"])
     assert np.linalg.norm(thumb - ref) / np.linalg.norm(ref) < 0.06
+
+
+@pytest.mark.gpu
+def test_sponza_pipeline_mean_against_the_reference_own_render(G):
+    """gdpt_renders/sponza_grad_path_trace/s_gp_256.exr and gdpt_renders/sponza.exr (768x575, written by the reference):
+    a tiny sphere light seen by BSDF sampling only is very noisy, so only the channel means are compared (measured: +2.5 %
+    and +4.5 % at 256 spp; asserted within 10 %). The reference's sponza *Path* renders are not usable as anchors: their
+    brightness equals the GradPath level, i.e. they were not produced by the shipped path_tracing (whose un-weighted
+    emitter-hit term roughly doubles the direct light of a small emitter)."""
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_images.json")))["reference_renders"]
+    sc = G.Scene(G.parse_scene(os.path.join(ROOT, "scenes", "sponza", "sponza.xml")))
+    out = sc.gradient_path_render(256, G.RNG_SAMPLE, alpha=0.04)
+    assert out.shape == (575, 768, 3) and np.isfinite(out).all()
+    for name in ("gdpt_renders/sponza_grad_path_trace/s_gp_256.exr", "gdpt_renders/sponza.exr"):
+        ratio = out.mean(axis=(0, 1)) / np.array(gold[name]["mean"])
+        assert np.all(np.abs(ratio - 1) < 0.10), (name, ratio)
