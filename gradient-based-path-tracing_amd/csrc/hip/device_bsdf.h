@@ -492,7 +492,9 @@ GD bool rd_sample(const Ctx &c, const GdptMaterial &m, D3 in, D2 ruv, double rw,
 // ROUGH = false drops the RoughPlastic / RoughDielectric cases: inlined into the switch they cost scenes that never take
 // them 20 % (Disney test scenes in the GradPath lane machine), so that kernel is built without them and scenes that do
 // use them go to the kernels built with ROUGH = true.
-template <bool ROUGH = true>
+// TWOSIDED = false likewise drops DisneyGlass / DisneyBSDF (the two heaviest lobes): the one-sided GradPath lane
+// machine never meets them.
+template <bool ROUGH = true, bool TWOSIDED = true>
 GD D3 bsdf_eval(const DevSceneView &sv, const GdptMaterial &m, D3 in, D3 out, const Vertex &v) {
     Ctx c{sv, v};
     switch (m.type) {
@@ -501,14 +503,14 @@ GD D3 bsdf_eval(const DevSceneView &sv, const GdptMaterial &m, D3 in, D3 out, co
         case GDPT_MAT_LAMBERTIAN: return lambert_eval(c, m.tex[0], in, out);
         case GDPT_MAT_DISNEY_DIFFUSE: return dd_eval(c, m.tex[0], m.tex[1], m.tex[2], in, out);
         case GDPT_MAT_DISNEY_METAL: return dm_eval(c, T3(c, m.tex[0]), m.tex[1], m.tex[2], in, out);
-        case GDPT_MAT_DISNEY_GLASS: return dg_eval(c, m.tex[0], m.tex[1], m.tex[2], m.eta, in, out);
+        case GDPT_MAT_DISNEY_GLASS: if (TWOSIDED) return dg_eval(c, m.tex[0], m.tex[1], m.tex[2], m.eta, in, out); else return splat(0);
         case GDPT_MAT_DISNEY_CLEARCOAT: return cc_eval(c, m.tex[0], in, out);
         case GDPT_MAT_DISNEY_SHEEN: return sh_eval(c, m.tex[0], m.tex[1], in, out);
-        case GDPT_MAT_DISNEY_BSDF: return db_eval(c, m, in, out);
+        case GDPT_MAT_DISNEY_BSDF: if (TWOSIDED) return db_eval(c, m, in, out); else return splat(0);
         default: return splat(0);
     }
 }
-template <bool ROUGH = true>
+template <bool ROUGH = true, bool TWOSIDED = true>
 GD double bsdf_pdf(const DevSceneView &sv, const GdptMaterial &m, D3 in, D3 out, const Vertex &v) {
     Ctx c{sv, v};
     switch (m.type) {
@@ -516,13 +518,13 @@ GD double bsdf_pdf(const DevSceneView &sv, const GdptMaterial &m, D3 in, D3 out,
         case GDPT_MAT_ROUGHDIELECTRIC: if (ROUGH) return rd_pdf(c, m, in, out); else return 0;
         case GDPT_MAT_LAMBERTIAN: case GDPT_MAT_DISNEY_DIFFUSE: case GDPT_MAT_DISNEY_SHEEN: return cos_pdf(c, in, out);
         case GDPT_MAT_DISNEY_METAL: return dm_pdf(c, m.tex[1], m.tex[2], in, out);
-        case GDPT_MAT_DISNEY_GLASS: return dg_pdf(c, m.tex[1], m.tex[2], m.eta, in, out);
+        case GDPT_MAT_DISNEY_GLASS: if (TWOSIDED) return dg_pdf(c, m.tex[1], m.tex[2], m.eta, in, out); else return 0;
         case GDPT_MAT_DISNEY_CLEARCOAT: return cc_pdf(c, m.tex[0], in, out);
-        case GDPT_MAT_DISNEY_BSDF: return db_pdf(c, m, in, out);
+        case GDPT_MAT_DISNEY_BSDF: if (TWOSIDED) return db_pdf(c, m, in, out); else return 0;
         default: return 0;
     }
 }
-template <bool ROUGH = true>
+template <bool ROUGH = true, bool TWOSIDED = true>
 GD bool bsdf_sample(const DevSceneView &sv, const GdptMaterial &m, D3 in, const Vertex &v, D2 ruv, double rw, BsdfSample &s) {
     Ctx c{sv, v};
     switch (m.type) {
@@ -531,9 +533,9 @@ GD bool bsdf_sample(const DevSceneView &sv, const GdptMaterial &m, D3 in, const 
         case GDPT_MAT_LAMBERTIAN: case GDPT_MAT_DISNEY_SHEEN: return cos_sample(c, in, ruv, 1.0, s);
         case GDPT_MAT_DISNEY_DIFFUSE: return dd_sample(c, m.tex[1], in, ruv, s);
         case GDPT_MAT_DISNEY_METAL: return dm_sample(c, m.tex[1], m.tex[2], in, ruv, s);
-        case GDPT_MAT_DISNEY_GLASS: return dg_sample(c, m.tex[1], m.eta, in, ruv, rw, s);
+        case GDPT_MAT_DISNEY_GLASS: if (TWOSIDED) return dg_sample(c, m.tex[1], m.eta, in, ruv, rw, s); else return false;
         case GDPT_MAT_DISNEY_CLEARCOAT: return cc_sample(c, m.tex[0], in, ruv, s);
-        case GDPT_MAT_DISNEY_BSDF: return db_sample(c, m, in, ruv, rw, s);
+        case GDPT_MAT_DISNEY_BSDF: if (TWOSIDED) return db_sample(c, m, in, ruv, rw, s); else return false;
         default: return false;
     }
 }

@@ -313,13 +313,13 @@ GD bool occluded_ctx(const DevSceneView &sv, const TraceCtx &tx, const Ray &ray,
 // ------------------------------------------------------------------------------------------------
 // material dispatch: Lambertian-only scenes get the three-line lobe inline, others the full switch
 // ------------------------------------------------------------------------------------------------
-template <bool LAMBERT, bool ROUGH = false>
+template <bool LAMBERT, bool ROUGH = false, bool TWOSIDED = false>
 GD bool mat_sample(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D2 ruv, double rw, BsdfSample &s) {
     if (LAMBERT) { Ctx c{sv, v}; return cos_sample(c, in, ruv, 1.0, s); }
-    return bsdf_sample<ROUGH>(sv, tx.materials[v.material_id], in, v, ruv, rw, s);
+    return bsdf_sample<ROUGH, TWOSIDED>(sv, tx.materials[v.material_id], in, v, ruv, rw, s);
 }
 // eval (f*|cos|) and solid-angle pdf together
-template <bool LAMBERT, bool ROUGH = false>
+template <bool LAMBERT, bool ROUGH = false, bool TWOSIDED = false>
 GD void mat_eval_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D3 out, D3 &f, double &pdf) {
     if (LAMBERT) {
         // src/materials/lambertian.inl:1-33 — eval and pdf share the clamped cosine
@@ -331,8 +331,8 @@ GD void mat_eval_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v
         return;
     }
     const GdptMaterial &m = tx.materials[v.material_id];
-    f = bsdf_eval<ROUGH>(sv, m, in, out, v);
-    pdf = bsdf_pdf<ROUGH>(sv, m, in, out, v);
+    f = bsdf_eval<ROUGH, TWOSIDED>(sv, m, in, out, v);
+    pdf = bsdf_pdf<ROUGH, TWOSIDED>(sv, m, in, out, v);
 }
 template <bool LAMBERT>
 GD double mat_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D3 out) {

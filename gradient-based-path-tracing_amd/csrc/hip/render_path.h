@@ -476,7 +476,7 @@ GD void path_lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth
             const double p1 = sv.light_pmf[light_id] * pdf_point_on_light(sv, light, pl, nv.position);
             if (G > 0 && p1 > 0) {
                 D3 f; double p2;
-                mat_eval_pdf<LAMBERT, true>(sv, tx, nv, dir_view, dir_light, f, p2);
+                mat_eval_pdf<LAMBERT, true, true>(sv, tx, nv, dir_view, dir_light, f, p2);
                 const D3 Le = (dot(pl.normal, -dir_light) <= 0) ? splat(0) : mk(light.intensity[0], light.intensity[1], light.intensity[2]);
                 D3 C1 = G * f * Le;
                 p2 *= G;
@@ -490,7 +490,7 @@ GD void path_lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth
             const double p1 = sv.light_pmf[light_id] * envmap_pdf(sv, -dir_light);
             if (p1 > 0) {
                 D3 f; double p2;
-                mat_eval_pdf<LAMBERT, true>(sv, tx, nv, dir_view, dir_light, f, p2);
+                mat_eval_pdf<LAMBERT, true, true>(sv, tx, nv, dir_view, dir_light, f, p2);
                 D3 C1 = 1.0 * f * envmap_emission(sv, -dir_light);
                 p2 *= 1.0;
                 const double w1 = (p1 * p1) / (p1 * p1 + p2 * p2);
@@ -504,10 +504,10 @@ GD void path_lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth
         L.rng_state = rng.state;
         BsdfSample bs;
         L.bounce_valid = 0;
-        if (mat_sample<LAMBERT, true>(sv, tx, nv, dir_view, ruv, rw, bs)) {                              // :200-203
+        if (mat_sample<LAMBERT, true, true>(sv, tx, nv, dir_view, ruv, rw, bs)) {                              // :200-203
             if (bs.eta != 0) L.eta_scale /= (bs.eta * bs.eta);
             D3 f; double pdf;
-            mat_eval_pdf<LAMBERT, true>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
+            mat_eval_pdf<LAMBERT, true, true>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
             if (pdf > 0) { L.bounce_valid = 1; L.dir_b = bs.dir_out; lp.set_f_pdf(f, pdf); }      // :263-266
         }
         L.org = nv.position;

@@ -137,8 +137,8 @@ GD void lane_step2(const DevSceneView &sv, const TraceCtx &tx, int max_depth, do
         L.rng_state = r.state;
         if (act == ACT_BOUNCE) lc.bounces++;
         const D3 dir_view = (act == ACT_BOUNCE) ? -ray.dir : -L.f;
-        sampled = mat_sample<false>(sv, tx, nv, dir_view, ruv, rw, bs);
-        if (sampled) mat_eval_pdf<false>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
+        sampled = mat_sample<false, false, true>(sv, tx, nv, dir_view, ruv, rw, bs);
+        if (sampled) mat_eval_pdf<false, false, true>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
     }
     if (need_resample) {
         if (!sampled || pdf <= 0.0) { off_done = true; off_alive = false; }         // :773-959
