@@ -2,6 +2,7 @@
 // per level per lane, can never overflow).
 #include "bvh.h"
 
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -43,6 +44,10 @@ struct Builder {
         for (uint32_t i = b; i < e; i++) bx.grow(pb[idx[i]].bmin, pb[idx[i]].bmax);
         return bx;
     }
+
+    // Leaf policy (build-time tuning knobs; the closest hit does not depend on the tree's shape).
+    uint32_t leaf_max = GDPT_LEAF_MAX_PRIMS;
+    float leaf_factor = 0.8f;
 
     int32_t make_leaf(uint32_t b, uint32_t e) {
         uint32_t first = (uint32_t)out.order.size();
@@ -111,7 +116,7 @@ struct Builder {
         uint32_t n = e - b;
         // Levels still available below this node, and levels a balanced tree over n prims needs.
         int remaining = GDPT_BVH_MAX_DEPTH - (level + 1);
-        int need_balanced = std::max(0, ceil_log2((n + GDPT_LEAF_MAX_PRIMS - 1) / GDPT_LEAF_MAX_PRIMS));
+        int need_balanced = std::max(0, ceil_log2((n + leaf_max - 1) / leaf_max));
         bool force_median = (need_balanced >= remaining);
         uint32_t m = split(b, e, force_median);
         int dl = 0, dr = 0;
@@ -127,7 +132,7 @@ struct Builder {
 
     int32_t build_child(uint32_t b, uint32_t e, int level, int *depth_out) {
         uint32_t n = e - b;
-        if (n <= GDPT_LEAF_MAX_PRIMS) {
+        if (n <= leaf_max) {
             // SAH leaf test for small ranges: keep splitting only if it pays (cost model: 1 per prim, 1 per node)
             bool make = true;
             if (n > 1 && level < GDPT_BVH_MAX_DEPTH) {
@@ -138,7 +143,7 @@ struct Builder {
                     std::vector<uint32_t> save(idx.begin() + b, idx.begin() + e);
                     uint32_t m = split(b, e, false);
                     float cost = (range_box(b, m).half_area() * (float)(m - b) + range_box(m, e).half_area() * (float)(e - m)) / fa + 1.0f;
-                    if (cost < (float)n * 0.8f) {
+                    if (cost < (float)n * leaf_factor) {
                         make = false;
                     } else {
                         std::copy(save.begin(), save.end(), idx.begin() + b);
@@ -155,6 +160,8 @@ struct Builder {
 
 BvhBuildResult build_bvh(const std::vector<PrimBounds> &bounds) {
     Builder bld(bounds);
+    if (const char *v = std::getenv("GDPT_BVH_LEAF_MAX")) bld.leaf_max = (uint32_t)std::min(std::max(std::atoi(v), 1), GDPT_LEAF_MAX_PRIMS);
+    if (const char *v = std::getenv("GDPT_BVH_LEAF_FACTOR")) bld.leaf_factor = (float)std::atof(v);
     uint32_t n = (uint32_t)bounds.size();
     if (n == 0) return std::move(bld.out);
     bld.idx.resize(n);
