@@ -36,6 +36,8 @@ T *upload(const std::vector<T> &v) {
 
 } // namespace
 
+static constexpr double kPresplitBudget = 0.0;   // extra references / primitives (GDPT_PRESPLIT overrides)
+
 struct GdptScene {
     int device = 0;
     DevSceneView view{};
@@ -108,6 +110,7 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     std::vector<DevSphere> spheres;
     std::vector<DevPrim> prim_in;          // input order (gid order, spheres last)
     std::vector<gdpt::PrimBounds> bounds;
+    std::vector<float> tri_verts;          // the fp32 triangles the intersection test sees (9 floats each), for presplit
     float lb[3], ub[3];
     for (int k = 0; k < 3; k++) { lb[k] = std::numeric_limits<float>::infinity(); ub[k] = -lb[k]; }
     for (int s = 0; s < desc->num_shapes; s++) {
@@ -142,6 +145,7 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
             ts.shape_id = s; ts.prim_id = t; ts.material_id = sh.material_id; ts.light_id = sh.area_light_id;
             ts.has_normals = sh.normals != nullptr; ts.has_uvs = sh.uvs != nullptr;
             for (int k = 0; k < 3; k++) { pr.v0[k] = v[0][k]; pr.e1[k] = v[1][k] - v[0][k]; pr.e2[k] = v[2][k] - v[0][k]; }
+            for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) tri_verts.push_back(v[i][k]);
             gdpt::precompute_tri_constants(pos64, pr.e1, pr.e2, &ts);
             pr.gid = (uint32_t)tris.size();
             tris.push_back(ts); prim_in.push_back(pr); bounds.push_back(pb);
@@ -167,7 +171,16 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
         spheres.push_back(sp); prim_in.push_back(pr); bounds.push_back(pb);
     }
 
-    gdpt::BvhBuildResult bvh = gdpt::build_bvh(bounds);
+    // large triangles of big meshes are referenced from several smaller boxes (host/presplit.cpp); scenes small enough
+    // for LDS keep one reference per primitive
+    std::vector<gdpt::PrimBounds> refs;
+    std::vector<uint32_t> ref_prim;
+    {
+        double budget = tris.size() >= 4096 ? kPresplitBudget : 0.0;
+        if (const char *e = std::getenv("GDPT_PRESPLIT")) budget = std::atof(e);
+        gdpt::presplit_triangles(bounds, tri_verts, budget, &refs, &ref_prim);
+    }
+    gdpt::BvhBuildResult bvh = gdpt::build_bvh(refs);
     {   // widen every child box: the traversal's slab test then needs no per-test padding (device_trace.h: box_hit)
         float ext = 0.f;
         for (int k = 0; k < 3; k++) if (ub[k] >= lb[k]) ext = std::max(ext, std::max(std::fabs(ub[k]), std::fabs(lb[k])));
@@ -188,8 +201,8 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     if (wide.stack_need > GDPT_BVH_MAX_DEPTH) throw std::runtime_error("gdpt_scene_upload: BVH deeper than the traversal stack (builder bug)");
     const std::vector<DevBvh4Node> &nodes4 = wide.nodes;
     sc->wide_stack_need = wide.stack_need;
-    std::vector<DevPrim> prims(prim_in.size());
-    for (size_t i = 0; i < bvh.order.size(); i++) prims[i] = prim_in[bvh.order[i]];
+    std::vector<DevPrim> prims(bvh.order.size());
+    for (size_t i = 0; i < bvh.order.size(); i++) prims[i] = prim_in[ref_prim[bvh.order[i]]];
     sc->bvh_depth = bvh.depth;
     if (bvh.depth > GDPT_BVH_MAX_DEPTH) throw std::runtime_error("gdpt_scene_upload: BVH deeper than the traversal stack (builder bug)");
 

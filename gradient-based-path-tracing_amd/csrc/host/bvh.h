@@ -30,3 +30,14 @@ struct WideBvh { std::vector<DevBvh4Node> nodes; int arity = 0, stack_need = 0; 
 WideBvh collapse_for_traversal(const std::vector<DevBvhNode> &nodes);
 
 } // namespace gdpt
+
+namespace gdpt {
+// Early split clipping of large triangles before the build: a triangle whose box is large is referenced from several
+// smaller boxes (each the box of the triangle clipped to a cell of its own box, rounded outward), so the SAH build can
+// separate geometry that long or diagonal triangles would otherwise glue together. References never change what a ray
+// hits — every piece points at the same primitive, the pieces cover the triangle — only how many boxes it visits.
+// `tri_verts`: 9 floats per triangle for the first tri_verts.size()/9 entries of `bounds` (spheres follow unsplit).
+// `budget` = extra references allowed as a fraction of the primitive count. ref_prim[r] = primitive of reference r.
+void presplit_triangles(const std::vector<PrimBounds> &bounds, const std::vector<float> &tri_verts, double budget,
+                        std::vector<PrimBounds> *refs, std::vector<uint32_t> *ref_prim);
+} // namespace gdpt
