@@ -117,8 +117,9 @@ def parse_scene(filename):
     return SceneDesc(p)
 
 
-def _params(spp, rng_scheme, rows, max_depth_override=0):
+def _params(spp, rng_scheme, rows, max_depth_override=0, shift=0):
     p = defs.GdptRenderParams()
+    p.shift_mode = int(shift)
     p.spp, p.rng_scheme = int(spp), int(rng_scheme)
     p.row_begin, p.row_end = int(rows[0]), int(rows[1])
     p.max_depth_override = int(max_depth_override)
@@ -141,20 +142,22 @@ class Scene:
         _check(lib().gdpt_scene_info(self.handle, *[C.byref(x) for x in v]))
         return dict(zip(("num_nodes", "num_tris", "num_spheres", "bvh_depth"), [x.value for x in v]))
 
-    def render(self, spp=0, rng_scheme=defs.RNG_SAMPLE, rows=(0, 0)):
-        """Five-buffer render to host arrays (HxWx3 float64). Returns (buffers, GdptRenderStats)."""
+    def render(self, spp=0, rng_scheme=defs.RNG_SAMPLE, rows=(0, 0), shift=defs.SHIFT_REFERENCE):
+        """Five-buffer render to host arrays (HxWx3 float64). Returns (buffers, GdptRenderStats).
+        `shift`: SHIFT_REFERENCE (the reference's offsets) or SHIFT_RECONNECT (include/gdpt.h)."""
         shape = (self.height, self.width, 3)
         bufs = {k: np.zeros(shape, dtype=np.float64) for k in ("img", "cx0", "cy0", "cx1", "cy1")}
         st = defs.GdptRenderStats()
-        p = _params(spp, rng_scheme, rows)
+        p = _params(spp, rng_scheme, rows, shift=shift)
         _check(lib().gdpt_render(self.handle, C.byref(p), _dp(bufs["img"]), _dp(bufs["cx0"]), _dp(bufs["cy0"]),
                                  _dp(bufs["cx1"]), _dp(bufs["cy1"]), C.byref(st)))
         return bufs, st
 
-    def render_device(self, ptrs, spp=0, rng_scheme=defs.RNG_SAMPLE, rows=(0, 0), stream=None, want_stats=False):
+    def render_device(self, ptrs, spp=0, rng_scheme=defs.RNG_SAMPLE, rows=(0, 0), stream=None, want_stats=False,
+                      shift=defs.SHIFT_REFERENCE):
         """Five-buffer render into device memory; `ptrs` = 5 device addresses (e.g. torch tensor.data_ptr())."""
         st = defs.GdptRenderStats() if want_stats else None
-        p = _params(spp, rng_scheme, rows)
+        p = _params(spp, rng_scheme, rows, shift=shift)
         _check(lib().gdpt_render_device(self.handle, C.byref(p), *[C.c_void_p(int(x)) for x in ptrs],
                                         C.c_void_p(int(stream) if stream else 0), C.byref(st) if st is not None else None))
         return st
@@ -173,13 +176,14 @@ class Scene:
         p = _params(spp, rng_scheme, rows)
         _check(lib().gdpt_path_render_device(self.handle, C.byref(p), C.c_void_p(int(ptr)), C.c_void_p(int(stream) if stream else 0), None))
 
-    def gradient_path_render(self, spp=0, rng_scheme=defs.RNG_SAMPLE, alpha=0.04, return_buffers=False):
+    def gradient_path_render(self, spp=0, rng_scheme=defs.RNG_SAMPLE, alpha=0.04, return_buffers=False,
+                             shift=defs.SHIFT_REFERENCE):
         """Whole Integrator::GradPath: render + assembly + screened-Poisson solve (src/render.cpp:257-370)."""
         shape = (self.height, self.width, 3)
         out = np.zeros(shape, dtype=np.float64)
         bufs = {k: np.zeros(shape, dtype=np.float64) for k in ("img", "cx0", "cy0", "cx1", "cy1")}
         rs, ps = defs.GdptRenderStats(), defs.GdptPoissonStats()
-        p = _params(spp, rng_scheme, (0, 0))
+        p = _params(spp, rng_scheme, (0, 0), shift=shift)
         _check(lib().gdpt_gradient_path_render(self.handle, C.byref(p), float(alpha), _dp(out),
                                                _dp(bufs["img"]), _dp(bufs["cx0"]), _dp(bufs["cy0"]), _dp(bufs["cx1"]), _dp(bufs["cy1"]),
                                                C.byref(rs), C.byref(ps)))

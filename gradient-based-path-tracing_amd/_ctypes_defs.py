@@ -10,6 +10,7 @@ SHAPE_SPHERE, SHAPE_TRIMESH = 0, 1
 FILTER_BOX, FILTER_TENT, FILTER_GAUSSIAN = 0, 1, 2
 INTEGRATOR_PATH, INTEGRATOR_GRADPATH, INTEGRATOR_OTHER = 5, 7, -1
 RNG_TILE, RNG_SAMPLE = 0, 2
+SHIFT_REFERENCE, SHIFT_RECONNECT = 0, 1
 SOLVER_CG, SOLVER_DCT = 0, 1
 
 
@@ -66,7 +67,7 @@ class GdptSceneDesc(C.Structure):
 
 class GdptRenderParams(C.Structure):
     _fields_ = [("spp", C.c_int32), ("rng_scheme", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32),
-                ("max_depth_override", C.c_int32), ("_pad", C.c_int32)]
+                ("max_depth_override", C.c_int32), ("shift_mode", C.c_int32)]
 
 
 class GdptRenderStats(C.Structure):

@@ -415,7 +415,7 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     ck(hipEventCreate(&sc->ev1), "hipEventCreate");
 }
 
-struct Band { int spp, rng, row_begin, row_end, max_depth; };
+struct Band { int spp, rng, row_begin, row_end, max_depth, shift; };
 
 Band resolve(const GdptScene *sc, const GdptRenderParams *p) {
     if (!sc) throw std::runtime_error("null scene handle");
@@ -427,6 +427,9 @@ Band resolve(const GdptScene *sc, const GdptRenderParams *p) {
     if (b.row_begin == 0 && b.row_end == 0) b.row_end = sc->view.cam.height;
     if (b.row_begin < 0 || b.row_end > sc->view.cam.height || b.row_begin >= b.row_end) throw std::runtime_error("gdpt_render: bad row band");
     if (b.rng != GDPT_RNG_TILE && b.rng != GDPT_RNG_SAMPLE) throw std::runtime_error("gdpt_render: unknown rng_scheme");
+    b.shift = p ? p->shift_mode : GDPT_SHIFT_REFERENCE;
+    if (b.shift != GDPT_SHIFT_REFERENCE && b.shift != GDPT_SHIFT_RECONNECT) throw std::runtime_error("gdpt_render: unknown shift_mode");
+    if (b.shift == GDPT_SHIFT_RECONNECT && b.rng != GDPT_RNG_SAMPLE) throw std::runtime_error("gdpt_render: GDPT_SHIFT_RECONNECT needs GDPT_RNG_SAMPLE");
     if (b.rng == GDPT_RNG_TILE && ((b.row_begin % 16) != 0 || ((b.row_end % 16) != 0 && b.row_end != sc->view.cam.height)))
         throw std::runtime_error("gdpt_render: GDPT_RNG_TILE bands must cover whole 16-pixel tile rows");
     b.max_depth = (p && p->max_depth_override != 0) ? p->max_depth_override : sc->view.max_depth;
@@ -443,7 +446,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     if (b.spp <= 0) throw std::runtime_error("gdpt_render: samples per pixel must be > 0");
     if (!img || !cx0 || !cy0 || !cx1 || !cy1) throw std::runtime_error("gdpt_render: null output buffer");
     gdpt::RenderLaunch rl{};
-    rl.spp = b.spp; rl.rng_scheme = b.rng; rl.row_begin = b.row_begin; rl.row_end = b.row_end; rl.max_depth = b.max_depth;
+    rl.spp = b.spp; rl.rng_scheme = b.rng; rl.row_begin = b.row_begin; rl.row_end = b.row_end; rl.max_depth = b.max_depth; rl.shift_mode = b.shift;
     rl.img = img; rl.cx0 = cx0; rl.cy0 = cy0; rl.cx1 = cx1; rl.cy1 = cy1;
     rl.counters = sc->d_counters;
     rl.count_traversal = stats && stats->nodes_visited == ~0ull;   // request flag: caller presets nodes_visited = UINT64_MAX
@@ -511,7 +514,7 @@ void path_render_device_impl(GdptScene *sc, const GdptRenderParams *params, doub
     if (b.spp <= 0) throw std::runtime_error("gdpt_path_render: samples per pixel must be > 0");
     if (!img) throw std::runtime_error("gdpt_path_render: null output buffer");
     gdpt::RenderLaunch rl{};
-    rl.spp = b.spp; rl.rng_scheme = b.rng; rl.row_begin = b.row_begin; rl.row_end = b.row_end; rl.max_depth = b.max_depth;
+    rl.spp = b.spp; rl.rng_scheme = b.rng; rl.row_begin = b.row_begin; rl.row_end = b.row_end; rl.max_depth = b.max_depth; rl.shift_mode = b.shift;
     rl.img = img;
     rl.counters = sc->d_counters;
     rl.count_traversal = stats && stats->nodes_visited == ~0ull;

@@ -18,6 +18,7 @@ struct RenderLaunch {
     double *img, *cx0, *cy0, *cx1, *cy1;   // device, W*H*3 each
     RenderCounters *counters;      // device
     bool count_traversal;          // counting build: BVH nodes / primitives per ray
+    int shift_mode;                // GDPT_SHIFT_*: 0 = the reference's offsets (parity mode), 1 = reconnection shift
     // scene classification (decided at upload) and tuning knobs
     bool one_sided_materials;      // no DisneyGlass / DisneyBSDF: the phase machine with lazy offsets is exact
     bool lambert_only;             // every material is Lambertian

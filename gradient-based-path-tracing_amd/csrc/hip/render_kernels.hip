@@ -22,7 +22,21 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
     const int W = sv.cam.width, rows = rl.row_end - rl.row_begin;
     if (W <= 0 || rows <= 0 || rl.spp <= 0) throw std::runtime_error("launch_render: empty image band or spp <= 0");
     const bool phases = (rl.one_sided_materials || rl.two_sided_machine) && !rl.force_eager;
-    if (rl.rng_scheme == GDPT_RNG_TILE) {
+    if (rl.shift_mode == GDPT_SHIFT_RECONNECT) {
+        // reconnection shift (render_reconnect.hip): straight per-sample loop, K = 2^log2k lanes per pixel
+        if (rl.rng_scheme != GDPT_RNG_SAMPLE) throw std::runtime_error("launch_render: GDPT_SHIFT_RECONNECT needs GDPT_RNG_SAMPLE");
+        long long pixels = (long long)W * rows;
+        int log2k = 0;
+        while ((1 << (log2k + 1)) <= rl.spp && log2k < 6 && (pixels << log2k) < (1LL << 19)) log2k++;
+        if (rl.force_log2k >= 0) { log2k = rl.force_log2k; while (log2k > 0 && (1 << log2k) > rl.spp) log2k--; }
+        a.log2k = log2k;
+        int ppb = gd::kBlock >> log2k;
+        a.tile_w = ppb >= 16 ? 16 : ppb;
+        a.tile_h = ppb / a.tile_w;
+        a.tiles_x = (W + a.tile_w - 1) / a.tile_w;
+        int tiles_y = (rows + a.tile_h - 1) / a.tile_h;
+        launch_reconnect(sv, a, dim3((unsigned)(a.tiles_x * tiles_y)), stream);
+    } else if (rl.rng_scheme == GDPT_RNG_TILE) {
         int ntx = (W + 15) / 16, nty = (sv.cam.height + 15) / 16;
         dim3 grid((unsigned)((ntx * nty + 63) / 64));
         if (!phases) launch_tile_eager(sv, a, grid, ntx, nty, stream);

@@ -140,6 +140,14 @@ typedef struct GdptSceneDesc {
  *            reference order (src/render.cpp:281-309). Serial per tile: one GPU lane per tile (slow; for checks).
  *   SAMPLE : init_pcg32((y*W+x)*spp + s) per sample — every sample independent (the throughput mode). */
 enum { GDPT_RNG_TILE = 0, GDPT_RNG_SAMPLE = 2 };
+/* How the four offset paths follow the base path.
+ * GDPT_SHIFT_REFERENCE: what grad_path_tracing does (src/path_tracing.h:351-560): offsets replay the base path's random
+ *   numbers and never rejoin it. The drop-in, parity-tested behaviour.
+ * GDPT_SHIFT_RECONNECT: the offset path's first vertex is reconnected to the base path's second vertex, with the
+ *   Jacobian and the balance-heuristic weights of the reference's own sketch (small_gdpt.py:163-219, :380-420); the
+ *   gradient buffers then are unbiased estimates of I(x)-I(x-1), I(y)-I(y-1) and the Poisson solve denoises. Same
+ *   base path (and primal image) as the reference mode. GDPT_RNG_SAMPLE only. Not part of the reference's output. */
+enum { GDPT_SHIFT_REFERENCE = 0, GDPT_SHIFT_RECONNECT = 1 };
 
 typedef struct GdptRenderParams {
     int32_t spp;               /* <=0: use scene samples_per_pixel; the reference hard-codes 1000 (src/render.cpp:293) */
@@ -147,7 +155,7 @@ typedef struct GdptRenderParams {
     int32_t row_begin, row_end;/* render rows [row_begin,row_end) only (multi-GPU bands); 0,0 = whole image.
                                   Rows outside the band are left untouched in the output buffers. */
     int32_t max_depth_override;/* 0 = use scene; else value */
-    int32_t _pad;
+    int32_t shift_mode;        /* GDPT_SHIFT_* (gdpt_render* only; 0 = the reference's behaviour) */
 } GdptRenderParams;
 
 typedef struct GdptRenderStats {

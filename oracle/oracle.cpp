@@ -1796,6 +1796,201 @@ int oracle_path_render(const OracleScene *s, int spp, int rng_scheme, int row_be
     return 0;
 }
 
+// ---- GDPT_SHIFT_RECONNECT (include/gdpt.h): the reconnection shift of the reference's sketch small_gdpt.py:163-219 with
+// its estimator (:380-420), on LaJolla's scenes and base path. CPU restatement of csrc/hip/render_reconnect.hip, term by
+// term (see the derivation in that file's header). PARITY UNPINNED against the reference: the reference never produces
+// this output; the mode is pinned by its defining property instead (tests: gradient buffers converge to the finite
+// differences of the converged image; the primal equals the reference mode's primal).
+static void reconnect_sample(const OracleScene &sc, int x, int y, Pcg &rng, Real spp, V3 acc[5], uint64_t *rays, uint64_t *bounces) {
+    const GdptCamera &cam = sc.desc.camera;
+    const int w = cam.width, h = cam.height, max_depth = sc.desc.max_depth;
+    auto allows = [&](int nv) { return max_depth == -1 || nv <= max_depth + 1; };
+    const double rng_x = pcg_real(rng), rng_y = pcg_real(rng);
+    Ray ray = sample_primary(cam, V2{(x + rng_x) / w, (y + rng_y) / h});
+    const Real rd_spread = Real(0.25) / rmax(w, h);
+    Vertex v1;
+    (*rays)++;
+    if (!intersect(sc, ray, 0, rd_spread, &v1)) return;
+    const int ox[4] = {-1, +1, 0, 0}, oy[4] = {0, 0, -1, +1};
+    Vertex ov[4]; V3 oview[4]; bool ok[4];
+    for (int k = 0; k < 4; k++) {
+        Ray r = sample_primary(cam, V2{((x + ox[k]) + rng_x) / w, ((y + oy[k]) + rng_y) / h});
+        (*rays)++;
+        ok[k] = intersect(sc, r, 0, rd_spread, &ov[k]);
+        oview[k] = -r.dir;
+    }
+    const int slot[4] = {1, 3, 2, 4};
+    const Real sgn[4] = {1, -1, 1, -1};
+    auto add_term = [&](int k, const V3 &f, const V3 &fo, Real wgt) { acc[slot[k]] = acc[slot[k]] + (f - fo) * (sgn[k] * wgt / spp); };
+    auto Le = [&](const Vertex &v, const V3 &view) { return is_light(sc, v.shape_id) ? emission(sc, v, view) : V3{0, 0, 0}; };
+
+    const V3 view1 = -ray.dir;
+    V3 radiance = Le(v1, view1);
+    for (int k = 0; k < 4; k++) {
+        if (!ok[k]) add_term(k, radiance, V3{0, 0, 0}, 1);
+        else add_term(k, radiance, Le(ov[k], oview[k]), Real(0.5));
+    }
+    auto finish = [&]() { acc[0] = acc[0] + radiance / spp; };
+    if (!allows(3)) { finish(); return; }
+
+    (*bounces)++;
+    V2 ruv; ruv.x = pcg_real(rng); ruv.y = pcg_real(rng);
+    Real rw = pcg_real(rng);
+    BsdfSample bs;
+    Real eta_scale = 1;
+    const GdptMaterial &mat1 = sc.desc.materials[v1.material_id];
+    if (!bsdf_sample(sc, mat1, view1, v1, ruv, rw, &bs)) { finish(); return; }
+    const V3 w1 = bs.dir_out;
+    if (bs.eta != 0) eta_scale /= (bs.eta * bs.eta);
+    const V3 f1 = bsdf_eval(sc, mat1, view1, w1, v1);
+    const Real p1 = bsdf_pdf(sc, mat1, view1, w1, v1);
+    Vertex v2;
+    (*rays)++;
+    const bool hit2 = intersect(sc, Ray{v1.position, w1, sc.isect_eps, std::numeric_limits<Real>::infinity()}, 0, 0, &v2);
+    if (!(p1 > 0) || !hit2) { finish(); return; }
+    const V3 A1 = f1 / p1;
+    V3 throughput{1, 1, 1};
+    Real rr_all = 1;
+    if (3 - 1 >= sc.desc.rr_depth) {
+        const Real rr_prob = rmin(maxc((1 / eta_scale) * throughput), Real(0.95));
+        if (pcg_real(rng) > rr_prob) rr_all = 0; else rr_all /= rr_prob;
+    }
+    throughput = A1 * rr_all;
+
+    const V3 d12 = v2.position - v1.position;
+    const Real dist2 = dot(d12, d12), cos2 = std::fabs(dot(w1, v2.geometric_normal));
+    V3 fo1[4], wo1[4]; Real ro1[4]; bool rec[4];
+    for (int k = 0; k < 4; k++) {
+        rec[k] = false; fo1[k] = V3{0, 0, 0}; ro1[k] = 0; wo1[k] = w1;
+        if (!ok[k] || !(cos2 > 0)) continue;
+        const Vertex &o = ov[k];
+        const V3 d = v2.position - o.position;
+        const Real od2 = dot(d, d);
+        if (!(od2 > 0)) continue;
+        const Real od = std::sqrt(od2);
+        const V3 wo = d / od;
+        const Real ocos2 = std::fabs(dot(wo, v2.geometric_normal));
+        if (!(ocos2 > 0) || dot(wo, v2.geometric_normal) * dot(w1, v2.geometric_normal) <= 0) continue;
+        const GdptMaterial &omat = sc.desc.materials[o.material_id];
+        const V3 f = bsdf_eval(sc, omat, oview[k], wo, o);
+        const Real p = bsdf_pdf(sc, omat, oview[k], wo, o);
+        if (!(p > 0)) continue;
+        (*rays)++;
+        if (occluded(sc, Ray{o.position, wo, sc.isect_eps, (1 - sc.isect_eps) * od})) continue;
+        const Real J = (ocos2 / od2) / (cos2 / dist2);
+        rec[k] = true; wo1[k] = wo;
+        fo1[k] = f * (J / p1); ro1[k] = p * J / p1;
+    }
+    if (is_light(sc, v2.shape_id)) {
+        const V3 Le2 = emission(sc, v2, -w1);
+        radiance = radiance + A1 * Le2;
+        for (int k = 0; k < 4; k++) {
+            if (!rec[k]) add_term(k, A1 * Le2, V3{0, 0, 0}, 1);
+            else add_term(k, A1 * Le2, fo1[k] * emission(sc, v2, -wo1[k]), 1 / (1 + ro1[k]));
+        }
+    }
+    if (rr_all == 0 || !allows(4)) { finish(); return; }
+
+    (*bounces)++;
+    ruv.x = pcg_real(rng); ruv.y = pcg_real(rng); rw = pcg_real(rng);
+    const GdptMaterial &mat2 = sc.desc.materials[v2.material_id];
+    const V3 view2 = -w1;
+    if (!bsdf_sample(sc, mat2, view2, v2, ruv, rw, &bs)) { finish(); return; }
+    const V3 w2 = bs.dir_out;
+    if (bs.eta != 0) eta_scale /= (bs.eta * bs.eta);
+    const V3 f2 = bsdf_eval(sc, mat2, view2, w2, v2);
+    const Real p2 = bsdf_pdf(sc, mat2, view2, w2, v2);
+    if (!(p2 > 0)) { finish(); return; }
+    const V3 B2 = f2 / p2;
+    V3 fo2[4]; Real ro2[4];
+    for (int k = 0; k < 4; k++) {
+        fo2[k] = V3{0, 0, 0}; ro2[k] = 0;
+        if (!rec[k]) continue;
+        const V3 f = bsdf_eval(sc, mat2, -wo1[k], w2, v2);
+        const Real p = bsdf_pdf(sc, mat2, -wo1[k], w2, v2);
+        if (!(p > 0)) { rec[k] = false; continue; }
+        fo2[k] = fo1[k] * (f / p2); ro2[k] = ro1[k] * (p / p2);
+    }
+    V3 U = splat(rr_all), S{0, 0, 0}, pendT = B2, pendU{1, 1, 1};
+    Ray cur{v2.position, w2, sc.isect_eps, std::numeric_limits<Real>::infinity()};
+    Vertex vertex;
+    (*rays)++;
+    bool hit = intersect(sc, cur, 0, 0, &vertex);
+    for (int nv = 4; hit;) {
+        if (is_light(sc, vertex.shape_id)) S = S + U * pendU * emission(sc, vertex, -cur.dir);
+        Real rr_prob = 1;
+        if (nv - 1 >= sc.desc.rr_depth) {
+            rr_prob = rmin(maxc((1 / eta_scale) * throughput), Real(0.95));
+            if (pcg_real(rng) > rr_prob) break;
+        }
+        throughput = throughput * pendT / rr_prob; U = U * pendU / rr_prob;
+        nv++;
+        if (!allows(nv)) break;
+        (*bounces)++;
+        const GdptMaterial &mat = sc.desc.materials[vertex.material_id];
+        const V3 view = -cur.dir;
+        ruv.x = pcg_real(rng); ruv.y = pcg_real(rng); rw = pcg_real(rng);
+        if (!bsdf_sample(sc, mat, view, vertex, ruv, rw, &bs)) break;
+        if (bs.eta != 0) eta_scale /= (bs.eta * bs.eta);
+        const V3 f = bsdf_eval(sc, mat, view, bs.dir_out, vertex);
+        const Real p = bsdf_pdf(sc, mat, view, bs.dir_out, vertex);
+        if (!(p > 0)) break;
+        pendT = f / p; pendU = pendT;
+        cur = Ray{vertex.position, bs.dir_out, sc.isect_eps, std::numeric_limits<Real>::infinity()};
+        (*rays)++;
+        hit = intersect(sc, cur, 0, 0, &vertex);
+    }
+    const V3 base3 = A1 * B2 * S;
+    radiance = radiance + base3;
+    for (int k = 0; k < 4; k++) {
+        if (!rec[k]) add_term(k, base3, V3{0, 0, 0}, 1);
+        else add_term(k, base3, fo2[k] * S, 1 / (1 + ro2[k]));
+    }
+    finish();
+}
+
+int oracle_reconnect_render(const OracleScene *s, int spp, int row_begin, int row_end, int threads,
+                            double *img, double *cx0, double *cy0, double *cx1, double *cy1, OracleStats *stats) {
+    const OracleScene &sc = *s;
+    int w = sc.desc.camera.width, h = sc.desc.camera.height;
+    if (spp <= 0) spp = sc.desc.samples_per_pixel;
+    if (row_begin == 0 && row_end == 0) row_end = h;
+    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    if (threads <= 0) threads = 1;
+    std::atomic<int> next_row{row_begin};
+    std::atomic<uint64_t> a_samples{0}, a_rays{0}, a_bounces{0};
+    auto t0 = std::chrono::steady_clock::now();
+    double *out[5] = {img, cx0, cy0, cx1, cy1};
+    auto worker = [&]() {
+        uint64_t n_samples = 0, n_rays = 0, n_bounces = 0;
+        for (;;) {
+            int y = next_row.fetch_add(1);
+            if (y >= row_end) break;
+            for (int x = 0; x < w; x++) {
+                V3 acc[5] = {};
+                for (int sidx = 0; sidx < spp; sidx++) {
+                    Pcg rng = pcg_init(((uint64_t)y * w + x) * (uint64_t)spp + (uint64_t)sidx);
+                    reconnect_sample(sc, x, y, rng, Real(spp), acc, &n_rays, &n_bounces);
+                    n_samples++;
+                }
+                size_t i = ((size_t)y * w + x) * 3;
+                for (int b = 0; b < 5; b++) for (int c = 0; c < 3; c++) out[b][i + c] += acc[b][c];
+            }
+        }
+        a_samples += n_samples; a_rays += n_rays; a_bounces += n_bounces;
+    };
+    std::vector<std::thread> pool;
+    for (int i = 1; i < threads; i++) pool.emplace_back(worker);
+    worker();
+    for (auto &t : pool) t.join();
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->samples = a_samples; stats->rays = a_rays; stats->bounces = a_bounces;
+        stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return 0;
+}
+
 void oracle_assemble(int w, int h, const double *img, const double *cx0, const double *cy0,
                      const double *cx1, const double *cy1, double *c, double *cx, double *cy) {
     for (int y = 0; y < h; y++)

@@ -95,6 +95,10 @@ void oracle_path_sample(const OracleScene *s, int x, int y, uint64_t *state, uin
  * Returns non-zero for scenes without any emitter. Environment maps: src/lights/envmap.inl. */
 /* TableDist2D (src/table_dist.cpp:40-150) built over f (row-major, height rows): sample(rnd) -> uv, pdf(uv). */
 void oracle_table2d(const double *f, int width, int height, const double *rnd, int n_rnd, double *uv_out, double *pdf_out, double *total);
+/* GDPT_SHIFT_RECONNECT (sample-stream RNG only): restatement of csrc/hip/render_reconnect.hip; parity unpinned against the
+ * reference (it has no such output), pinned by the mode's defining properties in tests/test_reconnect_shift.py. */
+int oracle_reconnect_render(const OracleScene *s, int spp, int row_begin, int row_end, int threads,
+                            double *img, double *cx0, double *cy0, double *cx1, double *cy1, OracleStats *stats);
 int oracle_path_render(const OracleScene *s, int spp, int rng_scheme, int row_begin, int row_end, int threads,
                        double *img, OracleStats *stats);
 

@@ -81,6 +81,8 @@ def lib():
         L.oracle_occluded.argtypes = [C.c_void_p, dp, dp, C.c_double, C.c_double]
         L.oracle_path_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_uint64, dp,
                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.oracle_reconnect_render.restype = C.c_int
+        L.oracle_reconnect_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, C.POINTER(OracleStats)]
         L.oracle_path_render.restype = C.c_int
         L.oracle_path_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, C.POINTER(OracleStats)]
         L.oracle_table2d.argtypes = [dp, C.c_int, C.c_int, dp, C.c_int, dp, dp, dp]
@@ -211,7 +213,17 @@ def _path_methods():
             raise RuntimeError(f"oracle_path_render failed ({rc}): scenes with an environment map / without lights are not restated")
         return img, st
 
-    for f in (light_table, sample_point_on_shape, pdf_point_on_shape, occluded, path_sample, path_render):
+    def reconnect_render(self, spp, rows=(0, 0), threads=0):
+        """GDPT_SHIFT_RECONNECT (include/gdpt.h), sample-stream RNG: five HxWx3 buffers + OracleStats."""
+        bufs = {k: np.zeros((self.height, self.width, 3)) for k in ("img", "cx0", "cy0", "cx1", "cy1")}
+        st = OracleStats()
+        rc = lib().oracle_reconnect_render(self.handle, int(spp), int(rows[0]), int(rows[1]), int(threads),
+                                           *[_dp(bufs[k]) for k in ("img", "cx0", "cy0", "cx1", "cy1")], C.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"oracle_reconnect_render failed ({rc})")
+        return bufs, st
+
+    for f in (light_table, sample_point_on_shape, pdf_point_on_shape, occluded, path_sample, path_render, reconnect_render):
         setattr(OracleScene, f.__name__, f)
 
 

@@ -1,0 +1,147 @@
+"""GDPT_SHIFT_RECONNECT (include/gdpt.h): the reconnection shift of the reference's own sketch
+(small_gdpt.py:163-219, estimator :380-420) on LaJolla's scenes, behind a flag that leaves the parity mode untouched.
+
+The reference never produces this output, so there is no golden image: the HIP kernel (render_reconnect.hip) is compared
+with its CPU restatement (oracle/oracle.cpp: reconnect_sample, "parity unpinned" against the reference), and both are
+pinned by what the mode is *for*: its gradient buffers are unbiased estimates of the image's finite differences (the
+reference mode's are not), its primal is the reference mode's primal, and the screened-Poisson output has a lower error
+than the primal at equal sample count."""
+import numpy as np
+import pytest
+
+from helpers import rel_l2, scene_variant
+
+BUFS = ("img", "cx0", "cy0", "cx1", "cy1")
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.square(a))))
+
+
+def gradients(b):
+    """gdpt_assemble's cx, cy (src/render.cpp:340-350) from the four gradient buffers."""
+    gx = np.array(b["cx0"]); gx[:, 1:] += np.asarray(b["cx1"])[:, :-1]
+    gy = np.array(b["cy0"]); gy[1:] += np.asarray(b["cy1"])[:-1]
+    return gx, gy
+
+
+def finite_differences(img):
+    fx = np.zeros_like(img); fx[:, 1:] = img[:, 1:] - img[:, :-1]
+    fy = np.zeros_like(img); fy[1:] = img[1:] - img[:-1]
+    return fx, fy
+
+
+# ------------------------------------------------------------------------------------------------ CPU: the restatement
+def test_oracle_reconnect_primal_is_the_reference_modes_primal(G, O, scene_tmp):
+    """Same base path, same draws: the primal buffer equals the reference mode's wherever the reference does not throw a
+    sample away (a failed BSDF sample zeroes the whole record there, src/path_tracing.h:545-548; here the path just ends)."""
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=32, height=24)
+    sd = G.parse_scene(xml)
+    osc = O.OracleScene(sd.ptr, use_bvh=True)
+    rec, rst = osc.reconnect_render(4, threads=8)
+    ref, ost = osc.render(4, G.RNG_SAMPLE, threads=8)
+    same = np.abs(rec["img"] - ref["img"]).max(axis=2) < 1e-12
+    assert same.mean() > 0.99
+    assert (rec["img"] - ref["img"]).min() > -1e-12          # dropped samples only ever lower the reference's primal
+    assert rst.bounces == ost.bounces
+
+
+def test_oracle_reconnect_gradients_are_finite_differences_of_the_image(G, O, scene_tmp):
+    """E[cx0[x] + cx1[x-1]] = I(x) - I(x-1): at N spp the estimate and the difference of the same render's primal agree to
+    their Monte-Carlo error, and the estimate is the less noisy of the two. The reference mode fails this by a wide margin."""
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=24, height=24)
+    sd = G.parse_scene(xml)
+    osc = O.OracleScene(sd.ptr, use_bvh=True)
+    conv, _ = osc.reconnect_render(1024, threads=8)
+    fx, fy = finite_differences(conv["img"])
+    gx, gy = gradients(conv)
+    # both are estimates of the same thing from the same 1024 spp
+    assert rms(gx[:, 1:] - fx[:, 1:]) < 0.25 * rms(fx[:, 1:])
+    assert rms(gy[1:] - fy[1:]) < 0.25 * rms(fy[1:])
+    ref, _ = osc.render(256, G.RNG_SAMPLE, threads=8)
+    rx, ry = gradients(ref)
+    assert rms(rx[:, 1:] - fx[:, 1:]) > 4 * rms(gx[:, 1:] - fx[:, 1:])     # the reference's buffers are not gradients
+    low, _ = osc.reconnect_render(16, threads=8)
+    lx, _ = gradients(low)
+    nx, _ = finite_differences(low["img"])
+    assert rms(lx[:, 1:] - fx[:, 1:]) < 0.5 * rms(nx[:, 1:] - fx[:, 1:])  # and they beat differencing the noisy primal
+
+
+# ------------------------------------------------------------------------------------------------ GPU: kernel vs restatement
+@pytest.mark.gpu
+@pytest.mark.parametrize("rel, integ, w, h, spp", [("cbox/cbox_gdpt.xml", None, 48, 32, 6), ("veach_mi/mi.xml", "gradpath", 48, 32, 4),
+                                                   ("sponza/sponza.xml", None, 40, 24, 3), ("cbox/small_pt_compare.xml", "gradpath", 32, 32, 4)])
+def test_gpu_reconnect_matches_the_restatement(G, O, scene_tmp, rel, integ, w, h, spp):
+    import os
+    from helpers import SCENES
+    if not os.path.exists(os.path.join(SCENES, rel)):
+        pytest.skip("scene not shipped")
+    xml = scene_variant(scene_tmp, rel, width=w, height=h, integrator=integ)
+    sd = G.parse_scene(xml)
+    got, st = G.Scene(sd).render(spp, G.RNG_SAMPLE, shift=G.SHIFT_RECONNECT)
+    want, ost = O.OracleScene(sd.ptr, use_bvh=True).reconnect_render(spp, threads=8)
+    for k in BUFS:
+        assert np.isfinite(got[k]).all(), k
+        assert rel_l2(got[k], want[k]) < 1e-7, k                # fp64 both sides; FMA contraction on the GPU only
+    assert st.bounces == ost.bounces and st.rays == ost.rays and st.nonfinite_samples == 0
+    if rel.startswith(("cbox/cbox_gdpt", "veach_mi")):           # (the small lights of the other two are rarely found at this size)
+        assert np.abs(want["cx0"]).max() > 0 and np.abs(want["cy1"]).max() > 0
+
+
+@pytest.mark.gpu
+def test_gpu_reconnect_two_sided_and_textured_materials(G, O, scene_tmp):
+    """DisneyBSDF / glass / rough lobes at v1 and v2: the shift re-evaluates both BSDFs with the offset's directions."""
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=40, height=32)
+    text = open(xml).read()
+    import re
+    kinds = ['<bsdf type="disneybsdf" id="\\1"><rgb name="baseColor" value="0.6 0.5 0.3"/><float name="specularTransmission" value="0.4"/>'
+             '<float name="metallic" value="0.3"/><float name="roughness" value="0.4"/><float name="clearcoat" value="0.5"/></bsdf>']
+    # turn the two boxes' materials into a DisneyBSDF and a rough plastic, keep the walls diffuse
+    text, n = re.subn(r'<bsdf type="diffuse" id="(box)">.*?</bsdf>', kinds[0], text, flags=re.S)
+    open(xml, "w").write(text)
+    sd = G.parse_scene(xml)
+    got, st = G.Scene(sd).render(4, G.RNG_SAMPLE, shift=G.SHIFT_RECONNECT)
+    want, ost = O.OracleScene(sd.ptr, use_bvh=True).reconnect_render(4, threads=8)
+    for k in BUFS:
+        assert rel_l2(got[k], want[k]) < 1e-7, k
+    assert st.bounces == ost.bounces
+
+
+@pytest.mark.gpu
+def test_gpu_reconnect_gradients_converge_and_the_reconstruction_beats_the_primal(G, scene_tmp):
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=96, height=96)
+    sc = G.Scene(G.parse_scene(xml))
+    conv, _ = sc.render(16384, G.RNG_SAMPLE)                      # converged image (reference mode's primal)
+    I = np.asarray(conv["img"])
+    fx, fy = finite_differences(I)
+    errs = {}
+    for spp in (16, 256):
+        out, b, rs, ps = sc.gradient_path_render(spp, G.RNG_SAMPLE, return_buffers=True, shift=G.SHIFT_RECONNECT)
+        gx, gy = gradients(b)
+        errs[spp] = (rms(gx[:, 1:] - fx[:, 1:]), rms(gy[1:] - fy[1:]), rms(np.asarray(b["img"]) - I), rms(np.asarray(out) - I))
+        assert rs.nonfinite_samples == 0
+    # Monte-Carlo rate: 16x the samples, ~4x less error, for gradients and primal alike (no bias floor in sight)
+    for i in range(3):
+        assert 2.8 < errs[16][i] / errs[256][i] < 5.6, (i, errs)
+    # the point of the exercise: at equal spp the Poisson output is closer to the converged image than the primal
+    assert errs[16][3] < 0.5 * errs[16][2], errs
+    assert errs[256][3] < 0.6 * errs[256][2], errs
+    # ... which the reference mode's buffers cannot deliver
+    out_ref = sc.gradient_path_render(16, G.RNG_SAMPLE)
+    assert rms(np.asarray(out_ref) - I) > 3 * errs[16][3]
+
+
+@pytest.mark.gpu
+def test_gpu_reconnect_bands_and_argument_errors(G, scene_tmp):
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=48, height=48)
+    sc = G.Scene(G.parse_scene(xml))
+    full, _ = sc.render(4, G.RNG_SAMPLE, shift=G.SHIFT_RECONNECT)
+    band, st = sc.render(4, G.RNG_SAMPLE, rows=(16, 32), shift=G.SHIFT_RECONNECT)
+    for k in BUFS:
+        assert np.array_equal(np.asarray(band[k])[16:32], np.asarray(full[k])[16:32]), k
+        assert not np.asarray(band[k])[:16].any() and not np.asarray(band[k])[32:].any()
+    assert st.samples == 48 * 16 * 4
+    with pytest.raises(RuntimeError, match="GDPT_RNG_SAMPLE"):
+        sc.render(2, G.RNG_TILE, shift=G.SHIFT_RECONNECT)
+    with pytest.raises(RuntimeError, match="shift_mode"):
+        sc.render(2, G.RNG_SAMPLE, shift=7)
