@@ -26,6 +26,7 @@ namespace gd {
 struct ShiftV1 { Vertex v; D3 dir_view; bool ok; };
 
 // One base sample and its four shifted copies, accumulated into `acc` (already divided by spp).
+template <class TC>
 GD void grad_sample_reconnect(const DevSceneView &sv, const TraceCtx &tx, int max_depth, int x, int y, Pcg &rng, double spp,
                               AccReg &acc, LaneCounters &lc, TraceCounters &tc) {
     const DevCamera &cam = sv.cam;
@@ -34,13 +35,13 @@ GD void grad_sample_reconnect(const DevSceneView &sv, const TraceCtx &tx, int ma
     Ray ray = sample_primary(cam, (x + rng_x) / w, (y + rng_y) / h);
     const double rd_spread = 0.25 / (double)max(w, h);
     Vertex v1;
-    if (!intersect_ctx<TraceHbm>(sv, tx, ray, rd_spread, v1, lc, tc)) return;
+    if (!intersect_ctx<TC>(sv, tx, ray, rd_spread, v1, lc, tc)) return;
     ShiftV1 sh[4];
 #pragma unroll 1
     for (int k = 0; k < 4; k++) {
         const int ox = (k == 0) ? -1 : (k == 1 ? 1 : 0), oy = (k == 2) ? -1 : (k == 3 ? 1 : 0);
         Ray r = sample_primary(cam, ((x + ox) + rng_x) / w, ((y + oy) + rng_y) / h);
-        sh[k].ok = intersect_ctx<TraceHbm>(sv, tx, r, rd_spread, sh[k].v, lc, tc);
+        sh[k].ok = intersect_ctx<TC>(sv, tx, r, rd_spread, sh[k].v, lc, tc);
         sh[k].dir_view = -r.dir;
     }
     // signs of (f - f'J) per buffer: cx0, cx1, cy0, cy1 = acc slots 1, 3, 2, 4
@@ -74,7 +75,7 @@ GD void grad_sample_reconnect(const DevSceneView &sv, const TraceCtx &tx, int ma
     double rw = pcg_real(rng);
     BsdfSample bs;
     double eta_scale = 1.0;
-    const GdptMaterial &mat1 = sv.materials[v1.material_id];
+    const GdptMaterial &mat1 = tx.materials[v1.material_id];
     if (!bsdf_sample(sv, mat1, dir_view1, v1, ruv, rw, bs)) { acc.add(0, radiance / spp); return; }
     const D3 w1 = bs.dir_out;
     if (bs.eta != 0) eta_scale /= (bs.eta * bs.eta);
@@ -82,7 +83,7 @@ GD void grad_sample_reconnect(const DevSceneView &sv, const TraceCtx &tx, int ma
     const double p1 = bsdf_pdf(sv, mat1, dir_view1, w1, v1);
     Ray r1; r1.org = v1.position; r1.dir = w1; r1.tnear = sv.isect_eps; r1.tfar = __builtin_huge_val();
     Vertex v2;
-    const bool hit2 = intersect_ctx<TraceHbm>(sv, tx, r1, 0.0, v2, lc, tc);
+    const bool hit2 = intersect_ctx<TC>(sv, tx, r1, 0.0, v2, lc, tc);
     if (!(p1 > 0) || !hit2) { acc.add(0, radiance / spp); return; }
     const D3 A1 = f1 / p1;
     // Russian roulette exactly as the parity mode places it: after the emitter term of the vertex just reached, from
@@ -114,12 +115,12 @@ GD void grad_sample_reconnect(const DevSceneView &sv, const TraceCtx &tx, int ma
         const double ocos2 = fabs(dot(wo, v2.gn));
         // the offset must see v2 on the side the base path arrived at
         if (!(ocos2 > 0) || dot(wo, v2.gn) * dot(w1, v2.gn) <= 0) continue;
-        const GdptMaterial &omat = sv.materials[o.material_id];
+        const GdptMaterial &omat = tx.materials[o.material_id];
         const D3 f = bsdf_eval(sv, omat, sh[k].dir_view, wo, o);
         const double p = bsdf_pdf(sv, omat, sh[k].dir_view, wo, o);
         if (!(p > 0)) continue;
         Ray sr; sr.org = o.position; sr.dir = wo; sr.tnear = sv.isect_eps; sr.tfar = (1 - sv.isect_eps) * od;
-        if (occluded_ctx<TraceHbm>(sv, tx, sr, lc, tc)) continue;
+        if (occluded_ctx<TC>(sv, tx, sr, lc, tc)) continue;
         const double J = (ocos2 / od2) / (cos2 / dist2);
         rec[k] = true; wo1[k] = wo;
         fo1[k] = f * (J / p1); ro1[k] = p * J / p1;
@@ -140,7 +141,7 @@ GD void grad_sample_reconnect(const DevSceneView &sv, const TraceCtx &tx, int ma
     // ---- bounce at v2 ----
     lc.bounces++;
     ruv.x = pcg_real(rng); ruv.y = pcg_real(rng); rw = pcg_real(rng);
-    const GdptMaterial &mat2 = sv.materials[v2.material_id];
+    const GdptMaterial &mat2 = tx.materials[v2.material_id];
     const D3 dir_view2 = -w1;
     if (!bsdf_sample(sv, mat2, dir_view2, v2, ruv, rw, bs)) { acc.add(0, radiance / spp); return; }
     const D3 w2 = bs.dir_out;
@@ -165,7 +166,7 @@ GD void grad_sample_reconnect(const DevSceneView &sv, const TraceCtx &tx, int ma
     D3 pendT = B2, pendU = splat(1.0);     // factor of the bounce just taken: enters after its Russian roulette
     Ray cur; cur.org = v2.position; cur.dir = w2; cur.tnear = sv.isect_eps; cur.tfar = __builtin_huge_val();
     Vertex vertex;
-    bool hit = intersect_ctx<TraceHbm>(sv, tx, cur, 0.0, vertex, lc, tc);
+    bool hit = intersect_ctx<TC>(sv, tx, cur, 0.0, vertex, lc, tc);
     for (int num_vertices = 4; hit;) {
         if (vertex.light_id >= 0) S = S + U * pendU * emission(sv, vertex, -cur.dir);
         double rr_prob = 1;
@@ -177,7 +178,7 @@ GD void grad_sample_reconnect(const DevSceneView &sv, const TraceCtx &tx, int ma
         num_vertices++;
         if (!loop_allows(max_depth, num_vertices)) break;
         lc.bounces++;
-        const GdptMaterial &mat = sv.materials[vertex.material_id];
+        const GdptMaterial &mat = tx.materials[vertex.material_id];
         const D3 dir_view = -cur.dir;
         ruv.x = pcg_real(rng); ruv.y = pcg_real(rng); rw = pcg_real(rng);
         if (!bsdf_sample(sv, mat, dir_view, vertex, ruv, rw, bs)) break;
@@ -187,7 +188,7 @@ GD void grad_sample_reconnect(const DevSceneView &sv, const TraceCtx &tx, int ma
         if (!(p > 0)) break;
         pendT = f / p; pendU = pendT;
         cur.org = vertex.position; cur.dir = bs.dir_out;
-        hit = intersect_ctx<TraceHbm>(sv, tx, cur, 0.0, vertex, lc, tc);
+        hit = intersect_ctx<TC>(sv, tx, cur, 0.0, vertex, lc, tc);
     }
     const D3 base3 = A1 * B2 * S;
     radiance = radiance + base3;
@@ -200,10 +201,15 @@ GD void grad_sample_reconnect(const DevSceneView &sv, const TraceCtx &tx, int ma
     acc.add(0, radiance / spp);
 }
 
+// LDS_SCENE: nodes (BVH4 form), primitive records, shading table and materials are copied into the block's LDS first
+// (scenes of cbox size), exactly as the lane machine does.
+template <bool LDS_SCENE>
 __global__ __launch_bounds__(kBlock, 2) void gdpt_render_reconnect(DevSceneView sv, KernelArgs a) {
     __shared__ int s_stack[GDPT_BVH_MAX_DEPTH * kBlock];
+    __shared__ __attribute__((aligned(16))) unsigned char s_scene[LDS_SCENE ? kLdsSceneBytes : 16];
+    using TC = TraceCfg<true, true, !LDS_SCENE>;
     const int tid = threadIdx.x;
-    TraceCtx tx = setup_trace<false, true>(sv, nullptr, s_stack, tid, kBlock, a.count != 0);
+    TraceCtx tx = setup_trace<LDS_SCENE, true>(sv, s_scene, s_stack, tid, kBlock, a.count != 0);
     const int K = 1 << a.log2k;
     const int c = tid & (K - 1), p = tid >> a.log2k;
     const int px = p % a.tile_w, py = p / a.tile_w;
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_reconnect(DevSceneView 
         const unsigned long long base = ((unsigned long long)y * W + x) * (unsigned long long)a.spp;
         for (int s = s0; s < s1; s++) {
             Pcg rng = pcg_init(base + (unsigned long long)s);
-            grad_sample_reconnect(sv, tx, a.max_depth, x, y, rng, (double)a.spp, acc, lc, tc);
+            grad_sample_reconnect<TC>(sv, tx, a.max_depth, x, y, rng, (double)a.spp, acc, lc, tc);
         }
     }
     Accum sum = acc.result();
@@ -230,7 +236,8 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_reconnect(DevSceneView 
 } // namespace gd
 
 namespace gdpt {
-void launch_reconnect(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, hipStream_t stream) {
-    hipLaunchKernelGGL(gd::gdpt_render_reconnect, grid, dim3(gd::kBlock), 0, stream, sv, a);
+void launch_reconnect(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, hipStream_t stream) {
+    if (lds) hipLaunchKernelGGL((gd::gdpt_render_reconnect<true>), grid, dim3(gd::kBlock), 0, stream, sv, a);
+    else hipLaunchKernelGGL((gd::gdpt_render_reconnect<false>), grid, dim3(gd::kBlock), 0, stream, sv, a);
 }
 } // namespace gdpt

@@ -24,7 +24,7 @@ int main(int argc, char *argv[]) {
         std::cout << "[Usage] ./lajolla [-t num_threads] [-o output_file_name] filename.xml" << std::endl;
         return 0;
     }
-    int num_threads = 0, spp = 0, device = 0, rng = GDPT_RNG_SAMPLE;
+    int num_threads = 0, spp = 0, device = 0, rng = GDPT_RNG_SAMPLE, shift = GDPT_SHIFT_REFERENCE;
     double alpha = 0.04;
     std::string outputfile = "";
     std::vector<std::string> filenames;
@@ -38,6 +38,12 @@ int main(int argc, char *argv[]) {
         else if (a == "--alpha") alpha = std::stod(next());
         else if (a == "--device") device = std::stoi(next());
         else if (a == "--rng") { std::string v = next(); rng = (v == "tile") ? GDPT_RNG_TILE : GDPT_RNG_SAMPLE; }
+        else if (a == "--shift") {        // extension: "reconnect" = GDPT_SHIFT_RECONNECT (include/gdpt.h); default = the reference's offsets
+            std::string v = next();
+            if (v == "reconnect") shift = GDPT_SHIFT_RECONNECT;
+            else if (v == "reference") shift = GDPT_SHIFT_REFERENCE;
+            else { std::cerr << "unknown --shift " << v << " (reference | reconnect)" << std::endl; return 2; }
+        }
         else filenames.push_back(a);
     }
     (void)num_threads;
@@ -66,7 +72,7 @@ int main(int argc, char *argv[]) {
         const int w = desc->camera.width, h = desc->camera.height;
         std::vector<double> image((size_t)w * h * 3);
         GdptRenderParams p{};
-        p.spp = spp; p.rng_scheme = rng;
+        p.spp = spp; p.rng_scheme = rng; p.shift_mode = shift;
         GdptRenderStats rs{};
         GdptPoissonStats ps{};
         // render() dispatches on the integrator (src/render.cpp:374-392)

@@ -145,3 +145,20 @@ def test_gpu_reconnect_bands_and_argument_errors(G, scene_tmp):
         sc.render(2, G.RNG_TILE, shift=G.SHIFT_RECONNECT)
     with pytest.raises(RuntimeError, match="shift_mode"):
         sc.render(2, G.RNG_SAMPLE, shift=7)
+
+
+@pytest.mark.gpu
+def test_cli_shift_flag(G, scene_tmp, tmp_path):
+    import os, subprocess
+    from helpers import ROOT
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=48, height=48)
+    exe = os.path.join(ROOT, "gradient-based-path-tracing_amd", "lajolla")
+    out = tmp_path / "o.pfm"
+    r = subprocess.run([exe, "--shift", "reconnect", "-o", str(out), "--spp", "4", xml], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    head = b"PF\n48 48\n-1\n"
+    img = np.frombuffer(out.read_bytes()[len(head):], dtype="<f4").reshape(48, 48, 3)
+    ref = G.Scene(G.parse_scene(xml)).gradient_path_render(4, G.RNG_SAMPLE, shift=G.SHIFT_RECONNECT)
+    assert np.array_equal(img, ref.astype(np.float32))
+    r = subprocess.run([exe, "--shift", "bogus", xml], capture_output=True, text=True)
+    assert r.returncode == 2 and "reference | reconnect" in r.stderr

@@ -29,3 +29,12 @@ for name, rel, w, h, spp in (("P cbox path 512x512 64spp", "cbox/cbox_gdpt.xml",
     img, st = sc.path_render(spp, G.RNG_SAMPLE)
     print(f"{name}: render {st.render_ms:.2f} ms = {st.samples / st.render_ms / 1e3:.1f} Msamples/s, rays/sample {st.rays / st.samples:.2f}, "
           f"bounces/sample {st.bounces / st.samples:.2f}, nonfinite {st.nonfinite_samples}", flush=True)
+# GDPT_SHIFT_RECONNECT: straight-loop kernel, HBM scene
+for name, rel, w, h, integ, spp in (("R cbox reconnect 512x512 16spp", "cbox/cbox_gdpt.xml", 512, 512, None, 16), ("R cbox reconnect 512x512 256spp", "cbox/cbox_gdpt.xml", 512, 512, None, 256),
+                                    ("R sponza reconnect 1280x720 16spp", "sponza/sponza.xml", 1280, 720, None, 16), ("R veach_mi reconnect 768x512 64spp", "veach_mi/mi.xml", 768, 512, "gradpath", 64)):
+    xml = scene_variant(tmp, rel, width=w, height=h, integrator=integ)
+    sc = G.Scene(G.parse_scene(xml))
+    for _ in range(2):
+        out, bufs, rs, ps = sc.gradient_path_render(spp, G.RNG_SAMPLE, return_buffers=True, shift=G.SHIFT_RECONNECT)
+    print(f"{name}: render {rs.render_ms:.2f} ms = {rs.samples / rs.render_ms / 1e3:.1f} Msamples/s, rays/sample {rs.rays / rs.samples:.2f}, "
+          f"bounces/sample {rs.bounces / rs.samples:.2f}, nonfinite {rs.nonfinite_samples}", flush=True)
