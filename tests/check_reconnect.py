@@ -6,8 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gdpt_amd as G
 from helpers import scene_variant
 tmp = tempfile.mkdtemp()
-for name, rel, w, h, integ in (("cbox", "cbox/cbox_gdpt.xml", 128, 128, None), ("veach_mi", "veach_mi/mi.xml", 192, 128, "gradpath"),
-                               ("disney_bsdf", "disney_bsdf_test/disney_bsdf.xml", 128, 96, "gradpath")):
+for name, rel, w, h, integ in (("cbox", "cbox/cbox_gdpt.xml", 512, 512, None), ("veach_mi", "veach_mi/mi.xml", 384, 256, "gradpath"), ("sponza", "sponza/sponza.xml", 320, 180, None)):
     xml = scene_variant(tmp, rel, width=w, height=h, integrator=integ)
     sc = G.Scene(G.parse_scene(xml))
     ref, st = sc.render(8192, G.RNG_SAMPLE)                      # converged primal (parity mode)
