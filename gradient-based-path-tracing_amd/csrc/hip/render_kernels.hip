@@ -35,7 +35,7 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
         a.tile_h = ppb / a.tile_w;
         a.tiles_x = (W + a.tile_w - 1) / a.tile_w;
         int tiles_y = (rows + a.tile_h - 1) / a.tile_h;
-        launch_reconnect(sv, a, dim3((unsigned)(a.tiles_x * tiles_y)), rl.scene_fits_lds && rl.lds_wide, stream);
+        launch_reconnect(sv, a, dim3((unsigned)(a.tiles_x * tiles_y)), rl.scene_fits_lds && rl.lds_wide, rl.lambert_only, stream);
     } else if (rl.rng_scheme == GDPT_RNG_TILE) {
         int ntx = (W + 15) / 16, nty = (sv.cam.height + 15) / 16;
         dim3 grid((unsigned)((ntx * nty + 63) / 64));
