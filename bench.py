@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "cbox", "cbox_gdpt.xml"))
     ap.add_argument("--alpha", type=float, default=0.04)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shift", choices=("reference", "reconnect"), default="reference",
+                    help="offset-path shift: 'reference' = the reference's behaviour (the headline metric); 'reconnect' = the "
+                         "extension mode of DESIGN.md 4.4 (profiling runs only: a different workload, named in config.workload)")
     ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-oracle sample")
     return ap.parse_args()
 
@@ -74,6 +77,7 @@ def main():
     scene = G.Scene(sd, device=local_rank)
     W, H = scene.width, scene.height
     spp_total = args.spp * world
+    shift = G.SHIFT_RECONNECT if args.shift == "reconnect" else G.SHIFT_REFERENCE
     from gdpt_amd import sharding
     r0, r1 = sharding.band_rows(H, world, rank)      # whole 16-pixel tile rows per rank (src/render.cpp:271)
 
@@ -87,7 +91,7 @@ def main():
 
     def step(want_stats=False):
         rs = scene.render_device([ptr(bufs[k]) for k in names], spp=spp_total, rng_scheme=G.RNG_SAMPLE,
-                                 rows=(r0, r1), stream=stream, want_stats=want_stats)
+                                 rows=(r0, r1), stream=stream, want_stats=want_stats, shift=shift)
         if world > 1:            # exchange step 1: the last cy1 row of the band above (W*24 bytes, point to point)
             sharding.halo_exchange_cy1(dist, bufs["cy1"], H, world, rank)
         G.assemble_device(W, H, [ptr(bufs[k]) for k in names], [ptr(c), ptr(cx), ptr(cy)], stream=stream)
@@ -128,7 +132,7 @@ def main():
     # traversal counters from the counting build of the same kernel (one extra launch)
     cs = G.GdptRenderStats()
     cs.nodes_visited = 2 ** 64 - 1     # request flag understood by gdpt_render_device
-    p = G._params(spp_total, G.RNG_SAMPLE, (r0, r1))
+    p = G._params(spp_total, G.RNG_SAMPLE, (r0, r1), shift=shift)
     import ctypes as C
     G._check(G.lib().gdpt_render_device(scene.handle, C.byref(p), *[C.c_void_p(ptr(bufs[k])) for k in names],
                                         C.c_void_p(stream), C.byref(cs)))
@@ -143,7 +147,7 @@ def main():
     import glob
     tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
     tpath = tfiles[-1] if tfiles else ""
-    if world == 1 and args.spp == 16 and tpath:
+    if world == 1 and args.spp == 16 and tpath and args.shift == "reference":
         try:
             traffic = json.load(open(tpath))["render_traffic_bytes_per_launch"]
         except Exception:
@@ -160,13 +164,14 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"scenes/cbox/cbox_gdpt.xml Integrator::GradPath {W}x{H}, {args.spp} spp per GPU "
-                               f"({spp_total} spp total), render+assemble+Poisson(DCT-I as fp64 GEMM) per step",
+                               f"({spp_total} spp total), render+assemble+Poisson(DCT-I as fp64 GEMM) per step"
+                               + (" [shift=reconnect: extension mode, NOT the headline workload]" if args.shift == "reconnect" else ""),
                    "rng": "sample-stream PCG32", "sharding": f"{world} row bands, 1-row halo + one packed all-gather of c,cx,cy" if world > 1 else "single GPU",
                    "alpha": args.alpha},
         "render_ms": render_ms_avg, "render_msamples_per_s": samples_rank / render_ms_avg / 1e3 if render_ms_avg > 0 else 0.0,
         "poisson_ms": poisson_ms_avg, "poisson_iterations": iters,
         "rays_per_sample": cs.rays / max(1, cs.samples), "bounces_per_sample": cs.bounces / max(1, cs.samples),
-        "roofline": {"bound": "hbm", "kernel": "gdpt_render_phases", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "gdpt_render_phases" if args.shift == "reference" else "gdpt_render_reconnect", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": render_ms_avg,
                      "nodes_per_ray": cs.nodes_visited / max(1, cs.rays), "node_bytes": cs.node_bytes, "prims_per_ray": cs.tris_tested / max(1, cs.rays)},
