@@ -67,6 +67,22 @@ def test_oracle_reconnect_gradients_are_finite_differences_of_the_image(G, O, sc
     assert rms(lx[:, 1:] - fx[:, 1:]) < 0.5 * rms(nx[:, 1:] - fx[:, 1:])  # and they beat differencing the noisy primal
 
 
+def test_oracle_reconnect_row_bands_are_independent(G, O, scene_tmp):
+    """Multi-GPU sharding renders row bands with no collective inside the render: a band must not depend on
+    what the other ranks do. Offsets reach one row outside the band — through camera rays, never through other pixels'
+    buffers — so the band of a partial render equals the same rows of the full one, and the assembly halo is cy1's last
+    row exactly as in the reference mode."""
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=24, height=24)
+    sd = G.parse_scene(xml)
+    osc = O.OracleScene(sd.ptr, use_bvh=True)
+    full, _ = osc.reconnect_render(3, threads=8)
+    band, st = osc.reconnect_render(3, rows=(8, 16), threads=8)
+    for k in BUFS:
+        assert np.array_equal(band[k][8:16], full[k][8:16]), k
+        assert not band[k][:8].any() and not band[k][16:].any()
+    assert st.samples == 24 * 8 * 3
+
+
 # ------------------------------------------------------------------------------------------------ GPU: kernel vs restatement
 @pytest.mark.gpu
 @pytest.mark.parametrize("rel, integ, w, h, spp", [("cbox/cbox_gdpt.xml", None, 48, 32, 6), ("veach_mi/mi.xml", "gradpath", 48, 32, 4),
