@@ -105,6 +105,27 @@ def test_gpu_reconnect_matches_the_restatement(G, O, scene_tmp, rel, integ, w, h
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("max_depth, rr_depth", [(1, 5), (2, 5), (3, 5), (4, 5), (-1, 1), (-1, 2), (-1, 3), (6, 2)])
+def test_gpu_reconnect_depth_limits_and_early_roulette(G, O, scene_tmp, max_depth, rr_depth):
+    """maxDepth cuts the path before / at / after the reconnection vertex; rrDepth 1..3 puts Russian roulette on the
+    bounces at v1 and v2, i.e. into the factors that sit outside the shared tail (rr_all, pending factors)."""
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=40, height=24, max_depth=max_depth)
+    text = open(xml).read().replace('<integer name="maxDepth"', f'<integer name="rrDepth" value="{rr_depth}"/>\n\t\t<integer name="maxDepth"', 1)
+    open(xml, "w").write(text)
+    sd = G.parse_scene(xml)
+    assert sd.ptr.contents.rr_depth == rr_depth and sd.ptr.contents.max_depth == max_depth
+    got, st = G.Scene(sd).render(6, G.RNG_SAMPLE, shift=G.SHIFT_RECONNECT)
+    want, ost = O.OracleScene(sd.ptr, use_bvh=True).reconnect_render(6, threads=8)
+    for k in BUFS:
+        assert rel_l2(got[k], want[k]) < 1e-7 or (not np.asarray(want[k]).any() and not np.asarray(got[k]).any()), k
+    assert st.bounces == ost.bounces and st.rays == ost.rays
+    # the primal still is the reference mode's (same roulette decisions, same depth cut)
+    ref, rst = G.Scene(sd).render(6, G.RNG_SAMPLE)
+    d = np.asarray(got["img"]) - np.asarray(ref["img"])
+    assert (np.abs(d).max(axis=2) < 1e-9).mean() > 0.99 and st.bounces == rst.bounces
+
+
+@pytest.mark.gpu
 def test_gpu_reconnect_two_sided_and_textured_materials(G, O, scene_tmp):
     """DisneyBSDF / glass / rough lobes at v1 and v2: the shift re-evaluates both BSDFs with the offset's directions."""
     xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=40, height=32)
