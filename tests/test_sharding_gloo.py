@@ -128,3 +128,44 @@ def test_halo_exchange_and_packed_gather_match_global_assembly(tmp_path, world, 
         got = np.load(tmp_path / f"halo{r}.npz")
         for name, w in zip(("c", "cx", "cy"), want):
             assert np.array_equal(got[name], w), (r, name)
+
+
+def _reconnect_pipeline_worker(rank, world, port, xml, spp, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gdpt_amd as G
+    import oracle_py as O
+    from gdpt_amd import sharding
+    sd = G.parse_scene(xml)
+    H, W = sd.height, sd.width
+    r0, r1 = sharding.band_rows(H, world, rank)
+    band, _ = O.OracleScene(sd.ptr, use_bvh=True).reconnect_render(spp, rows=(r0, r1), threads=2)
+    mine = {}
+    for k, v in band.items():
+        t = torch.full((H, W, 3), -7.0, dtype=torch.float64)
+        t[r0:r1] = torch.from_numpy(v[r0:r1])
+        mine[k] = t
+    sharding.halo_exchange_cy1(dist, mine["cy1"], H, world, rank)
+    c, cx, cy = _assemble_np(*[mine[k].numpy() for k in ("img", "cx0", "cy0", "cx1", "cy1")])
+    parts = [torch.from_numpy(a.copy()) for a in (c, cx, cy)]
+    sharding.gather_packed(dist, parts, H, world, rank, {})
+    out = O.fourier_solve(*[t.numpy() for t in parts], 0.04)
+    np.save(os.path.join(out_dir, f"rec{rank}.npy"), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reconnect_mode_sharded_pipeline_matches_single_process(G, O, scene_tmp, tmp_path):
+    """bench.py's N>1 step (band render -> cy1 halo -> local assembly -> packed all-gather -> replicated Poisson solve) with
+    the GDPT_SHIFT_RECONNECT buffers: every rank ends with the single-process image, bit for bit."""
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=24, height=32)
+    sd = G.parse_scene(xml)
+    whole, _ = O.OracleScene(sd.ptr, use_bvh=True).reconnect_render(3, threads=4)
+    want = O.fourier_solve(*_assemble_np(*[whole[k] for k in ("img", "cx0", "cy0", "cx1", "cy1")]), 0.04)
+    port = _free_port()
+    mp.spawn(_reconnect_pipeline_worker, args=(2, port, xml, 3, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"rec{r}.npy"), want), r
