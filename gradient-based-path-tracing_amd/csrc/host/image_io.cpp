@@ -211,33 +211,45 @@ inline void piz_wdec16(uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) {
     const int aa = (d + bb - 0x8000) & 0xFFFF;
     b = (uint16_t)bb; a = (uint16_t)aa;
 }
+// Inverse of the PIZ 2-D wavelet. Source of the arithmetic: the OpenEXR file-format description of PIZ ("wav2Decode":
+// hierarchical Haar-like lifting on 16-bit words, the 14-bit form when every value is < 2^14 and the modulo-2^16 form
+// otherwise; piz_wdec14 / piz_wdec16 above are those two lifting steps and admit no other arithmetic). A level with
+// half-step p pairs the samples that sit on the stride-p lattice: (x, x+p) for x = 0, 2p, ... while x + 2p <= nx, and
+// the same in y; a lattice column (row) left without a partner — bit p of nx (ny) set — only takes part in the other
+// direction. Cells of one level are independent, so the level is written here as two separable sweeps over the lattice
+// (all vertical pairs, then all horizontal pairs) addressed by (x, y) indices, coarse to fine.
 void piz_wav2_decode(uint16_t *in, int nx, int ox, int ny, int oy, uint16_t mx) {
-    const bool w14 = mx < (1 << 14);
-    const int n = nx > ny ? ny : nx;
-    int p = 1, p2;
-    while (p <= n) p <<= 1;
-    p >>= 1; p2 = p; p >>= 1;
-    auto dec = [&](uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) { if (w14) piz_wdec14(l, h, a, b); else piz_wdec16(l, h, a, b); };
-    while (p >= 1) {
-        uint16_t *py = in, *ey = in + (ptrdiff_t)oy * (ny - p2);
-        const int oy1 = oy * p, oy2 = oy * p2, ox1 = ox * p, ox2 = ox * p2;
-        uint16_t i00, i01, i10, i11;
-        for (; py <= ey; py += oy2) {
-            uint16_t *px = py, *ex = py + (ptrdiff_t)ox * (nx - p2);
-            for (; px <= ex; px += ox2) {
-                uint16_t *p01 = px + ox1, *p10 = px + oy1, *p11 = p10 + ox1;
-                dec(*px, *p10, i00, i10);
-                dec(*p01, *p11, i01, i11);
-                dec(i00, i01, *px, *p01);
-                dec(i10, i11, *p10, *p11);
+    const bool narrow = mx < (1 << 14);
+    auto unlift = [&](uint16_t &lo, uint16_t &hi) {          // (average, difference) -> the two samples, in place
+        uint16_t a, b;
+        if (narrow) piz_wdec14(lo, hi, a, b); else piz_wdec16(lo, hi, a, b);
+        lo = a; hi = b;
+    };
+    auto at = [&](int x, int y) -> uint16_t & { return in[(ptrdiff_t)x * ox + (ptrdiff_t)y * oy]; };
+    int top = 1;                                             // coarsest full step: largest power of two <= min(nx, ny)
+    while (top * 2 <= (nx < ny ? nx : ny)) top *= 2;
+    for (int step = top, half = top / 2; half >= 1; step = half, half /= 2) {
+        const int cells_x = nx / step, cells_y = ny / step;  // complete cells per direction
+        const bool odd_x = (nx & half) != 0, odd_y = (ny & half) != 0;
+        // vertical pairs: both columns of every complete cell, plus the partnerless lattice column
+        for (int cy = 0; cy < cells_y; cy++) {
+            const int y = cy * step;
+            for (int cx = 0; cx < cells_x; cx++) {
+                unlift(at(cx * step, y), at(cx * step, y + half));
+                unlift(at(cx * step + half, y), at(cx * step + half, y + half));
             }
-            if (nx & p) { uint16_t *p10 = px + oy1; dec(*px, *p10, i00, *p10); *px = i00; }
+            if (odd_x) unlift(at(cells_x * step, y), at(cells_x * step, y + half));
         }
-        if (ny & p) {
-            uint16_t *px = py, *ex = py + (ptrdiff_t)ox * (nx - p2);
-            for (; px <= ex; px += ox2) { uint16_t *p01 = px + ox1; dec(*px, *p01, i00, *p01); *px = i00; }
+        // horizontal pairs: both rows of every complete cell, plus the partnerless lattice row
+        for (int cy = 0; cy < cells_y; cy++)
+            for (int r = 0; r < 2; r++) {
+                const int y = cy * step + r * half;
+                for (int cx = 0; cx < cells_x; cx++) unlift(at(cx * step, y), at(cx * step + half, y));
+            }
+        if (odd_y) {
+            const int y = cells_y * step;
+            for (int cx = 0; cx < cells_x; cx++) unlift(at(cx * step, y), at(cx * step + half, y));
         }
-        p2 = p; p >>= 1;
     }
 }
 // chan_words[c]: 1 for HALF, 2 for FLOAT / UINT channels (in file order)
@@ -521,9 +533,19 @@ void load_texture_file(const std::string &path, int channels, int *width, int *h
     bool v1 = std::memcmp(magic, "GDTEX1\n", 7) == 0, v2 = std::memcmp(magic, "GDTEX2\n", 7) == 0;
     if (!ifs || !(v1 || v2) || hdr[0] <= 0 || hdr[1] <= 0 || (hdr[2] != 1 && hdr[2] != 3))
         throw std::runtime_error("Failure when loading image: bad header in " + raw);
+    // sizes are checked against what the file can hold before anything is allocated from them
+    if (hdr[0] > 65536 || hdr[1] > 65536) throw std::runtime_error("Failure when loading image: implausible extent in " + raw);
+    const std::streamoff body = ifs.tellg();
+    ifs.seekg(0, std::ios::end);
+    const uint64_t remaining = (uint64_t)(ifs.tellg() - body);
+    ifs.seekg(body);
     *width = hdr[0]; *height = hdr[1];
     int fc = hdr[2];
-    std::vector<float> data((size_t)hdr[0] * hdr[1] * fc);
+    const uint64_t ntex = (uint64_t)hdr[0] * (uint64_t)hdr[1] * (uint64_t)fc;
+    if (v1 && ntex * sizeof(float) > remaining) throw std::runtime_error("Failure when loading image: truncated " + raw);
+    // v2: zlib expands at most ~1032:1, so a body this short cannot hold that many texels
+    if (v2 && (remaining < 4 || ntex > (remaining - 4) * 1040 + 64)) throw std::runtime_error("Failure when loading image: truncated " + raw);
+    std::vector<float> data((size_t)ntex);
     if (v1) {
         ifs.read((char *)data.data(), (std::streamsize)(data.size() * sizeof(float)));
         if (!ifs) throw std::runtime_error("Failure when loading image: truncated " + raw);
@@ -532,7 +554,8 @@ void load_texture_file(const std::string &path, int channels, int *width, int *h
         // A 1-channel request is reduced in 8 bits first, as stb does: y = (77 r + 150 g + 29 b) >> 8 (stb_image.h:1708).
         uint32_t zlen = 0;
         ifs.read((char *)&zlen, 4);
-        std::vector<unsigned char> z(zlen), u8((size_t)hdr[0] * hdr[1] * fc);
+        if (!ifs || (uint64_t)zlen > remaining - 4) throw std::runtime_error("Failure when loading image: truncated " + raw);
+        std::vector<unsigned char> z(zlen), u8((size_t)ntex);
         ifs.read((char *)z.data(), zlen);
         if (!ifs) throw std::runtime_error("Failure when loading image: truncated " + raw);
         uLongf out_len = (uLongf)u8.size();

@@ -115,30 +115,31 @@ inline int fx(float c) { return (int)(c * 4096 + 0.5); }
 // 64-bit intermediates: identical to stb's 32-bit arithmetic for every valid stream (whose values stay far inside 32
 // bits) and free of signed overflow on corrupt ones.
 typedef long long I64;
-struct Idct1D { I64 x0, x1, x2, x3, t0, t1, t2, t3; };
+// One 8-point inverse DCT pass. Source of the arithmetic: the Loeffler-Ligtenberg-Moschytz factorisation with 12-bit
+// fixed-point constants as the Independent JPEG Group's "slow integer" IDCT (jidctint.c) states it and as stb_image
+// evaluates it; bit-exact texels (tests/golden/ref_images.json holds the reference decoder's CRCs) admit no other
+// operation order, so the sums below keep that order. Output: even-part sums e[0..3] and odd-part sums o[0..3]; sample
+// k of the pass is e[k] + o[3-k] (k < 4) and e[7-k] - o[k-4] (k >= 4) after the caller's rounding shift.
+struct Idct1D { I64 x0, x1, x2, x3, t0, t1, t2, t3; };     // x = even part, t = odd part
 inline Idct1D idct_1d(I64 s0, I64 s1, I64 s2, I64 s3, I64 s4, I64 s5, I64 s6, I64 s7) {
     Idct1D r;
-    I64 p1, p2, p3, p4, p5, t0, t1, t2, t3;
-    p2 = s2; p3 = s6;
-    p1 = (p2 + p3) * fx(0.5411961f);
-    t2 = p1 + p3 * fx(-1.847759065f);
-    t3 = p1 + p2 * fx(0.765366865f);
-    p2 = s0; p3 = s4;
-    t0 = (p2 + p3) * 4096;
-    t1 = (p2 - p3) * 4096;
-    r.x0 = t0 + t3; r.x3 = t0 - t3; r.x1 = t1 + t2; r.x2 = t1 - t2;
-    t0 = s7; t1 = s5; t2 = s3; t3 = s1;
-    p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;
-    p5 = (p3 + p4) * fx(1.175875602f);
-    t0 = t0 * fx(0.298631336f);
-    t1 = t1 * fx(2.053119869f);
-    t2 = t2 * fx(3.072711026f);
-    t3 = t3 * fx(1.501321110f);
-    p1 = p5 + p1 * fx(-0.899976223f);
-    p2 = p5 + p2 * fx(-2.562915447f);
-    p3 = p3 * fx(-1.961570560f);
-    p4 = p4 * fx(-0.390180644f);
-    r.t3 = t3 + p1 + p4; r.t2 = t2 + p2 + p3; r.t1 = t1 + p2 + p4; r.t0 = t0 + p1 + p3;
+    // even part: rotation of (s2, s6) by 6*pi/16, butterfly of (s0, s4)
+    const I64 rot = (s2 + s6) * fx(0.5411961f);
+    const I64 even_b = rot + s6 * fx(-1.847759065f);
+    const I64 even_a = rot + s2 * fx(0.765366865f);
+    const I64 sum04 = (s0 + s4) * 4096, dif04 = (s0 - s4) * 4096;
+    r.x0 = sum04 + even_a; r.x3 = sum04 - even_a; r.x1 = dif04 + even_b; r.x2 = dif04 - even_b;
+    // odd part: four inputs, three shared rotations (the "z" terms of the factorisation)
+    const I64 z73 = s7 + s3, z51 = s5 + s1, z71 = s7 + s1, z53 = s5 + s3;
+    const I64 zall = (z73 + z51) * fx(1.175875602f);
+    const I64 q71 = zall + z71 * fx(-0.899976223f);
+    const I64 q53 = zall + z53 * fx(-2.562915447f);
+    const I64 q73 = z73 * fx(-1.961570560f);
+    const I64 q51 = z51 * fx(-0.390180644f);
+    r.t3 = s1 * fx(1.501321110f) + q71 + q51;
+    r.t2 = s3 * fx(3.072711026f) + q53 + q73;
+    r.t1 = s5 * fx(2.053119869f) + q53 + q51;
+    r.t0 = s7 * fx(0.298631336f) + q71 + q73;
     return r;
 }
 

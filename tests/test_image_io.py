@@ -2,6 +2,7 @@
 (src/image.cpp:135-173). Mirrors the reference's image round-trip test (src/tests/image.cpp:4-36)."""
 import struct
 
+import pytest
 import numpy as np
 
 
@@ -189,3 +190,33 @@ def test_decoders_reject_corrupt_input_without_crashing(G, tmp_path):
             except G.GdptError:
                 outcomes["rejected"] += 1
     assert outcomes["ok"] > 0 and outcomes["rejected"] > 0
+
+
+def test_gdtex_companion_rejects_lying_headers(G, tmp_path):
+    """A .gdtex companion whose header promises more texels (or a longer zlib body) than the file holds must be
+    refused before anything is allocated from the header; a well-formed one decodes (v1 fp32 and v2 zlib/8-bit)."""
+    import struct
+    import zlib
+    tex = (np.arange(4 * 3 * 3) % 251).astype(np.uint8).reshape(3, 4, 3)
+    z = zlib.compress(tex.tobytes(), 9)
+    good2 = b"GDTEX2\n" + struct.pack("<iiiI", 4, 3, 3, len(z)) + z
+    good1 = b"GDTEX1\n" + struct.pack("<iii", 4, 3, 3) + tex.astype(np.float32).tobytes()
+    for blob in (good1, good2):
+        p = tmp_path / "t.png"                      # unknown suffix -> the loader looks for the companion
+        (tmp_path / "t.png.gdtex").write_bytes(blob)
+        a = G.imread(str(p), 3)
+        assert a.shape == (3, 4, 3)
+    expect = np.float32(tex / np.float32(255.0)) ** np.float32(2.2)
+    assert np.abs(a - expect).max() < 1e-6         # v2 widened like stbi_loadf
+    bad = [
+        b"GDTEX1\n" + struct.pack("<iii", 60000, 60000, 3) + b"\0" * 64,            # 43 GB promised, 64 bytes there
+        b"GDTEX2\n" + struct.pack("<iiiI", 60000, 60000, 3, 16) + b"\0" * 16,       # ditto for the inflated size
+        b"GDTEX2\n" + struct.pack("<iiiI", 4, 3, 3, 0xFFFFFFF0) + z,                # 4 GB zlib body promised
+        b"GDTEX2\n" + struct.pack("<iiiI", 70000, 3, 3, len(z)) + z,                # extent cap
+        good2[:-3],                                                                 # truncated body
+        good1[:-5],
+    ]
+    for blob in bad:
+        (tmp_path / "t.png.gdtex").write_bytes(blob)
+        with pytest.raises(G.GdptError):
+            G.imread(str(tmp_path / "t.png"), 3)
