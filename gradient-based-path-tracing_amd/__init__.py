@@ -67,6 +67,8 @@ def lib():
         L.gdpt_imread.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(dp)]
         L.gdpt_image_free.argtypes = [dp]
         L.gdpt_bvh_check.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int32)]
+        L.gdpt_debug_knob_set.argtypes = [C.c_char_p, C.c_double]
+        L.gdpt_debug_knobs_reset.restype = None
         _LIB = L
     return _LIB
 
@@ -269,6 +271,46 @@ def shape_triangle_bounds(scene_desc):
         tri = pos[idx]                                   # T x 3 x 3
         out.append(np.concatenate([tri.min(axis=1), tri.max(axis=1)], axis=1))
     return np.concatenate(out, axis=0) if out else np.zeros((0, 6), np.float32)
+
+
+class debug_knobs:
+    """Test instrument (include/gdpt_debug.h): `with debug_knobs(force_eager=1, log2k=0): ...` forces an alternative
+    schedule for the calls inside the block and restores the product path afterwards. The library reads no environment
+    variable; manual sweep scripts under tests/ that take their settings from GDPT_* variables translate them through
+    debug_knobs.from_env() explicitly."""
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+
+    def __enter__(self):
+        for k, v in self.knobs.items():
+            _check(lib().gdpt_debug_knob_set(k.encode(), float(v)))
+        return self
+
+    def __exit__(self, *exc):
+        lib().gdpt_debug_knobs_reset()
+        return False
+
+    @staticmethod
+    def set(**knobs):
+        for k, v in knobs.items():
+            _check(lib().gdpt_debug_knob_set(k.encode(), float(v)))
+
+    @staticmethod
+    def reset():
+        lib().gdpt_debug_knobs_reset()
+
+    @staticmethod
+    def from_env(environ=None):
+        """GDPT_FORCE_EAGER=1 -> force_eager=1 ... for the manual sweep scripts (tests/sweep_*.py, tune_render.py)."""
+        environ = os.environ if environ is None else environ
+        names = ("force_eager", "log2k", "keep_frac", "search_frac", "blocks_per_cu", "no_lds_scene", "lds_wide",
+                 "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor")
+        lib().gdpt_debug_knobs_reset()
+        for n in names:
+            v = environ.get("GDPT_" + n.upper())
+            if v is not None:
+                _check(lib().gdpt_debug_knob_set(n.encode(), float(v)))
 
 
 def build_arch():

@@ -1,5 +1,6 @@
 // capi_host.cpp — host-only entry points of include/gdpt.h (scene ingest, image output, errors).
 #include "../../include/gdpt.h"
+#include "../../include/gdpt_debug.h"
 #include "capi_common.h"
 #include "host/bvh.h"
 #include "host/image_io.h"
@@ -19,6 +20,21 @@ static thread_local std::string g_last_error;
 void set_last_error(const std::string &msg) { g_last_error = msg; }
 } // namespace gdpt
 
+namespace gdpt {
+namespace {
+std::mutex g_knob_mu;
+std::map<std::string, double> g_knobs;     // test-only overrides, include/gdpt_debug.h
+const char *const kKnobNames[] = {"force_eager", "log2k", "keep_frac", "search_frac", "blocks_per_cu", "no_lds_scene", "lds_wide",
+                                  "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor"};
+} // namespace
+double debug_knob(const char *name, double def) {
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    if (g_knobs.empty()) return def;
+    auto it = g_knobs.find(name);
+    return it == g_knobs.end() ? def : it->second;
+}
+} // namespace gdpt
+
 namespace {
 std::mutex g_mu;
 std::map<GdptSceneDesc *, std::unique_ptr<gdpt::HostScene>> g_descs; // desc pointer -> owner
@@ -27,6 +43,21 @@ std::map<GdptSceneDesc *, std::unique_ptr<gdpt::HostScene>> g_descs; // desc poi
 extern "C" {
 
 const char *gdpt_last_error(void) { return gdpt::g_last_error.c_str(); }
+
+int gdpt_debug_knob_set(const char *name, double value) {
+    return gdpt::guarded([&]() {
+        if (!name) throw std::runtime_error("gdpt_debug_knob_set: null name");
+        bool known = false;
+        for (const char *k : gdpt::kKnobNames) if (std::strcmp(k, name) == 0) known = true;
+        if (!known) throw std::runtime_error(std::string("gdpt_debug_knob_set: unknown knob '") + name + "'");
+        std::lock_guard<std::mutex> lk(gdpt::g_knob_mu);
+        gdpt::g_knobs[name] = value;
+    });
+}
+void gdpt_debug_knobs_reset(void) {
+    std::lock_guard<std::mutex> lk(gdpt::g_knob_mu);
+    gdpt::g_knobs.clear();
+}
 
 int gdpt_parse_scene(const char *xml_path, GdptSceneDesc **out_desc) {
     return gdpt::guarded([&]() {

@@ -177,7 +177,7 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     std::vector<uint32_t> ref_prim;
     {
         double budget = tris.size() >= 4096 ? kPresplitBudget : 0.0;
-        if (const char *e = std::getenv("GDPT_PRESPLIT")) budget = std::atof(e);
+        budget = gdpt::debug_knob("presplit", budget);
         gdpt::presplit_triangles(bounds, tri_verts, budget, &refs, &ref_prim);
     }
     gdpt::BvhBuildResult bvh = gdpt::build_bvh(refs);
@@ -452,12 +452,13 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.count_traversal = stats && stats->nodes_visited == ~0ull;   // request flag: caller presets nodes_visited = UINT64_MAX
     rl.one_sided_materials = sc->one_sided && !sc->has_rough; rl.lambert_only = sc->lambert_only;
     rl.scene_fits_lds = gdpt::scene_fits_lds(sc->view.num_nodes, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->bvh_depth);
-    auto env_int = [](const char *name, int def) { const char *v = std::getenv(name); return v ? std::atoi(v) : def; };
-    rl.force_eager = env_int("GDPT_FORCE_EAGER", 0) != 0;           // tuning / A-B knobs (undocumented defaults are the product path)
-    rl.thresh_a = env_int("GDPT_KEEP_FRAC", -1); rl.thresh_c = env_int("GDPT_SEARCH_FRAC", -1);
-    rl.force_log2k = env_int("GDPT_LOG2K", -1);
+    // A/B overrides of the parity tests (include/gdpt_debug.h); every default below is the product path
+    auto env_int = [](const char *name, int def) { return gdpt::debug_knob_int(name, def); };
+    rl.force_eager = env_int("force_eager", 0) != 0;
+    rl.thresh_a = env_int("keep_frac", -1); rl.thresh_c = env_int("search_frac", -1);
+    rl.force_log2k = env_int("log2k", -1);
     rl.num_cus = sc->num_cus;
-    rl.blocks_per_cu = env_int("GDPT_BLOCKS_PER_CU", 0);
+    rl.blocks_per_cu = env_int("blocks_per_cu", 0);
     {
         size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, b.spp, rl.force_log2k);
         if (need > sc->partials_doubles) {
@@ -467,9 +468,9 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
         }
         rl.partials = sc->d_partials; rl.queue_head = sc->d_queue;
     }
-    if (env_int("GDPT_NO_LDS_SCENE", 0)) rl.scene_fits_lds = false;
+    if (env_int("no_lds_scene", 0)) rl.scene_fits_lds = false;
     // two-sided lobes (DisneyGlass, DisneyBSDF) without rough ones: lane machine with offsets replayed from a bounce log
-    rl.two_sided_machine = !sc->one_sided && !sc->has_rough && !rl.force_eager && b.rng == GDPT_RNG_SAMPLE && !env_int("GDPT_NO_TWOSIDED_MACHINE", 0);
+    rl.two_sided_machine = !sc->one_sided && !sc->has_rough && !rl.force_eager && b.rng == GDPT_RNG_SAMPLE && !env_int("no_twosided_machine", 0);
     if (rl.two_sided_machine) {
         const long long tiles = (long long)((sc->view.cam.width + 15) / 16) * ((b.row_end - b.row_begin + 15) / 16);
         const long long items = (tiles * 256) << gdpt::render_log2_chunks(b.spp, rl.force_log2k, (long long)sc->view.cam.width * (b.row_end - b.row_begin));
@@ -481,7 +482,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
         }
         rl.bounce_log = sc->d_bounce_log; rl.bounce_log_bytes = sc->bounce_log_bytes;
     }
-    rl.lds_wide = rl.scene_fits_lds && env_int("GDPT_LDS_WIDE", 1) != 0 &&
+    rl.lds_wide = rl.scene_fits_lds && env_int("lds_wide", 1) != 0 &&
                   gdpt::scene_fits_lds_wide(sc->view.num_nodes4, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->wide_stack_need);
     ck(hipMemsetAsync(sc->d_counters, 0, sizeof(gdpt::RenderCounters), stream), "hipMemsetAsync(counters)");
     if (stats) ck(hipEventRecord(sc->ev0, stream), "hipEventRecord");
@@ -518,13 +519,13 @@ void path_render_device_impl(GdptScene *sc, const GdptRenderParams *params, doub
     rl.img = img;
     rl.counters = sc->d_counters;
     rl.count_traversal = stats && stats->nodes_visited == ~0ull;
-    auto env_int = [](const char *name, int def) { const char *v = std::getenv(name); return v ? std::atoi(v) : def; };
-    rl.force_log2k = env_int("GDPT_LOG2K", -1);
-    rl.force_eager = env_int("GDPT_FORCE_EAGER", 0) != 0;
-    rl.thresh_a = env_int("GDPT_KEEP_FRAC", -1); rl.thresh_c = env_int("GDPT_SEARCH_FRAC", -1);
-    rl.num_cus = sc->num_cus; rl.blocks_per_cu = env_int("GDPT_BLOCKS_PER_CU", 0);
+    auto env_int = [](const char *name, int def) { return gdpt::debug_knob_int(name, def); };   // include/gdpt_debug.h
+    rl.force_log2k = env_int("log2k", -1);
+    rl.force_eager = env_int("force_eager", 0) != 0;
+    rl.thresh_a = env_int("keep_frac", -1); rl.thresh_c = env_int("search_frac", -1);
+    rl.num_cus = sc->num_cus; rl.blocks_per_cu = env_int("blocks_per_cu", 0);
     rl.lambert_only = sc->lambert_only;
-    rl.scene_fits_lds = !env_int("GDPT_NO_LDS_SCENE", 0) &&
+    rl.scene_fits_lds = !env_int("no_lds_scene", 0) &&
                         gdpt::scene_fits_lds_wide(sc->view.num_nodes4, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->wide_stack_need);
     {
         size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, b.spp, rl.force_log2k);
@@ -558,7 +559,10 @@ void path_render_device_impl(GdptScene *sc, const GdptRenderParams *params, doub
 
 extern "C" {
 
-const char *gdpt_build_arch(void) { return "gfx950"; }
+#ifndef GDPT_BUILD_ARCH
+#error "GDPT_BUILD_ARCH must name the --offload-arch the kernels were compiled for (csrc/Makefile passes it)"
+#endif
+const char *gdpt_build_arch(void) { return GDPT_BUILD_ARCH; }
 
 int gdpt_scene_upload(const GdptSceneDesc *desc, int device, GdptScene **out_scene) {
     return gdpt::guarded([&]() {
@@ -650,7 +654,7 @@ int gdpt_poisson_solve_device(int width, int height, const double *d_c, const do
                               void *stream, GdptPoissonStats *stats) {
     return gdpt::guarded([&]() {
         if (!d_c || !d_gx || !d_gy || !d_out) throw std::runtime_error("gdpt_poisson_solve_device: null buffer");
-        gdpt::PoissonResult r = gdpt::poisson_solve_device(width, height, d_c, d_gx, d_gy, dataCost, d_out, solver, tol, max_iters, (hipStream_t)stream);
+        gdpt::PoissonResult r = gdpt::poisson_solve_device(width, height, d_c, d_gx, d_gy, dataCost, d_out, solver, tol, max_iters, (hipStream_t)stream, stats != nullptr);
         if (stats) { stats->iterations = r.iterations; stats->solver = r.solver; stats->rel_residual = r.rel_residual; stats->solve_ms = r.solve_ms; }
     });
 }
@@ -671,7 +675,7 @@ int gdpt_poisson_solve_ex(int width, int height, const double *imgData, const do
             ck(hipMemcpy(d[0], imgData, bytes, hipMemcpyHostToDevice), "hipMemcpy");
             ck(hipMemcpy(d[1], imgGradX, bytes, hipMemcpyHostToDevice), "hipMemcpy");
             ck(hipMemcpy(d[2], imgGradY, bytes, hipMemcpyHostToDevice), "hipMemcpy");
-            gdpt::PoissonResult r = gdpt::poisson_solve_device(width, height, d[0], d[1], d[2], dataCost, d[3], solver, tol, max_iters, nullptr);
+            gdpt::PoissonResult r = gdpt::poisson_solve_device(width, height, d[0], d[1], d[2], dataCost, d[3], solver, tol, max_iters, nullptr, stats != nullptr);
             ck(hipMemcpy(imgOut, d[3], bytes, hipMemcpyDeviceToHost), "hipMemcpy");
             if (stats) { stats->iterations = r.iterations; stats->solver = r.solver; stats->rel_residual = r.rel_residual; stats->solve_ms = r.solve_ms; }
         } catch (...) { cleanup(); throw; }
@@ -699,7 +703,7 @@ int gdpt_gradient_path_render(GdptScene *scene, const GdptRenderParams *params, 
         GdptRenderStats local{};
         render_device_impl(scene, &p, scene->scene_spp, b[0], b[1], b[2], b[3], b[4], nullptr, rstats ? rstats : &local);
         gdpt::launch_assemble(w, h, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], nullptr);
-        gdpt::PoissonResult r = gdpt::poisson_solve_device(w, h, b[5], b[6], b[7], dataCost, b[8], GDPT_SOLVER_DCT, 0.0, 0, nullptr);
+        gdpt::PoissonResult r = gdpt::poisson_solve_device(w, h, b[5], b[6], b[7], dataCost, b[8], GDPT_SOLVER_DCT, 0.0, 0, nullptr, pstats != nullptr);
         if (pstats) { pstats->iterations = r.iterations; pstats->solver = r.solver; pstats->rel_residual = r.rel_residual; pstats->solve_ms = r.solve_ms; }
         ck(hipMemcpy(out_image, b[8], elems * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
         double *host[5] = {img, cx0, cy0, cx1, cy1};

@@ -11,10 +11,12 @@ void launch_assemble(int w, int h, const double *img, const double *cx0, const d
                      double *c, double *cx, double *cy, hipStream_t stream);
 
 // Screened Poisson solve on device buffers (W*H*3 doubles, interleaved RGB), reproducing fourierSolve
-// (src/render.cpp:172-254): same operator, mirror boundaries and DC override. Synchronises `stream`
-// (convergence is checked on the host between chunks of iterations).
+// (src/render.cpp:172-254): same operator, mirror boundaries and DC override.
+// GDPT_SOLVER_DCT only enqueues work on `stream` (no event, no host wait) unless `timed`, which brackets the solve with
+// HIP events and waits for it (PoissonResult::solve_ms; 0 otherwise). GDPT_SOLVER_CG synchronises `stream` in any
+// case: convergence is checked on the host between chunks of iterations. Scratch state is kept per (device, stream).
 PoissonResult poisson_solve_device(int w, int h, const double *d_c, const double *d_gx, const double *d_gy, double alpha,
-                                   double *d_out, int solver, double tol, int max_iters, hipStream_t stream);
+                                   double *d_out, int solver, double tol, int max_iters, hipStream_t stream, bool timed);
 
 void poisson_release_workspace();
 

@@ -25,6 +25,8 @@
 #include <chrono>
 #include <cmath>
 #include <vector>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -273,30 +275,28 @@ struct Workspace {
     gp::CgState *state = nullptr;
     gp::CgState *h_state = nullptr;   // pinned
     double *h_rel = nullptr;          // pinned
-    int device = -1;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // timing pair + chunk marker, created once
     void release() {
         for (double *p : {x, r, q, p0, p1, partials, rel}) if (p) hipFree(p);
         if (state) hipFree(state);
         if (h_state) hipHostFree(h_state);
         if (h_rel) hipHostFree(h_rel);
+        for (auto &e : ev) if (e) hipEventDestroy(e);
         *this = Workspace();
     }
     void ensure(size_t n) {
-        int dev = 0;
-        ck(hipGetDevice(&dev), "hipGetDevice");
-        if (n <= n3 && dev == device) return;
+        if (n <= n3) return;
         release();
-        device = dev; n3 = n;
+        n3 = n;
         for (double **p : {&x, &r, &q, &p0, &p1}) ck(hipMalloc((void **)p, n * sizeof(double)), "hipMalloc(poisson workspace)");
         ck(hipMalloc((void **)&partials, 10 * gp::kMaxBlocks * sizeof(double)), "hipMalloc(partials)");
         ck(hipMalloc((void **)&rel, sizeof(double)), "hipMalloc(rel)");
         ck(hipMalloc((void **)&state, sizeof(gp::CgState)), "hipMalloc(state)");
         ck(hipHostMalloc((void **)&h_state, sizeof(gp::CgState)), "hipHostMalloc");
         ck(hipHostMalloc((void **)&h_rel, sizeof(double)), "hipHostMalloc");
+        for (auto &e : ev) ck(hipEventCreate(&e), "hipEventCreate");
     }
 };
-Workspace g_ws;
-std::mutex g_ws_mu;
 
 } // namespace
 
@@ -309,35 +309,63 @@ struct DctPlan {
     double *d_mat = nullptr;   // C[j][k] = w_j cos(pi j k/(n-1)), row-major n x n
     double *d_lap = nullptr;   // 2 cos(pi i/(n-1)) (the caller adds -4 on the y axis)
 };
+// Transform matrices and eigenvalue tables depend on the extent only: one set per device, shared (read-only) by every
+// stream. Scratch buffers, the rocBLAS handle and the timing events belong to one (device, stream) pair, so solves on
+// different streams or devices (one host thread per GPU, gdpt_gradient_path_render_multi) never share mutable state.
+struct DctTables {
+    std::mutex mu;
+    std::vector<std::unique_ptr<DctPlan>> plans;
+    std::vector<std::pair<int, double *>> lap_y;
+    void release() {
+        for (auto &p : plans) { if (p->d_mat) hipFree(p->d_mat); if (p->d_lap) hipFree(p->d_lap); }
+        for (auto &l : lap_y) if (l.second) hipFree(l.second);
+        plans.clear(); lap_y.clear();
+    }
+};
 struct DctWorkspace {
-    int device = -1;
     rocblas_handle handle = nullptr;
-    DctPlan plans[2];          // [0] width, [1] height (same plan object when w == h is handled by lookup)
     size_t elems = 0;
     double *buf[2] = {nullptr, nullptr};
     double *partials = nullptr;
-    double *lap_y = nullptr; int lap_y_n = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
     void release() {
-        for (auto &p : plans) { if (p.d_mat) hipFree(p.d_mat); if (p.d_lap) hipFree(p.d_lap); p = DctPlan(); }
         for (auto &b : buf) { if (b) hipFree(b); b = nullptr; }
         if (partials) hipFree(partials);
-        if (lap_y) hipFree(lap_y);
         if (handle) rocblas_destroy_handle(handle);
+        for (auto &e : ev) if (e) hipEventDestroy(e);
         *this = DctWorkspace();
     }
 };
-DctWorkspace g_dct;
+struct StreamState {                  // everything a solve on one (device, stream) mutates
+    std::mutex mu;                    // held while a solve is being enqueued on this pair
+    Workspace cg;
+    DctWorkspace dct;
+};
+std::mutex g_registry_mu;
+std::map<std::pair<int, hipStream_t>, std::unique_ptr<StreamState>> g_streams;
+std::map<int, std::unique_ptr<DctTables>> g_tables;
+
+StreamState &stream_state(int dev, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_registry_mu);
+    auto &slot = g_streams[{dev, stream}];
+    if (!slot) slot.reset(new StreamState());
+    return *slot;
+}
+DctTables &device_tables(int dev) {
+    std::lock_guard<std::mutex> lk(g_registry_mu);
+    auto &slot = g_tables[dev];
+    if (!slot) slot.reset(new DctTables());
+    return *slot;
+}
 
 void rb(rocblas_status st, const char *what) {
     if (st != rocblas_status_success) throw std::runtime_error(std::string(what) + ": rocBLAS status " + std::to_string((int)st));
 }
 
 // host tables, with the argument reduced exactly: cos(pi * ((j*k) mod 2(n-1)) / (n-1))
-void build_plan(DctPlan &p, int n) {
-    if (p.n == n) return;
-    if (p.d_mat) hipFree(p.d_mat);
-    if (p.d_lap) hipFree(p.d_lap);
-    p = DctPlan();
+const DctPlan &get_plan(DctTables &t, int n) {
+    for (auto &p : t.plans) if (p->n == n) return *p;
+    std::unique_ptr<DctPlan> p(new DctPlan());
     std::vector<double> m((size_t)n * n), lap(n), ctab(2 * (size_t)(n - 1));
     for (size_t i = 0; i < ctab.size(); i++) ctab[i] = std::cos(M_PI * (double)i / (double)(n - 1));
     for (int j = 0; j < n; j++) {
@@ -345,47 +373,56 @@ void build_plan(DctPlan &p, int n) {
         for (int k = 0; k < n; k++) m[(size_t)j * n + k] = wj * ctab[((size_t)j * k) % ctab.size()];
     }
     for (int i = 0; i < n; i++) lap[i] = 2.0 * std::cos(M_PI * i / (n - 1));     // ftLapX (:184-186)
-    ck(hipMalloc((void **)&p.d_mat, m.size() * sizeof(double)), "hipMalloc(dct matrix)");
-    ck(hipMalloc((void **)&p.d_lap, lap.size() * sizeof(double)), "hipMalloc(dct lap)");
-    ck(hipMemcpy(p.d_mat, m.data(), m.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(dct matrix)");
-    ck(hipMemcpy(p.d_lap, lap.data(), lap.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(dct lap)");
-    p.n = n;
+    ck(hipMalloc((void **)&p->d_mat, m.size() * sizeof(double)), "hipMalloc(dct matrix)");
+    ck(hipMalloc((void **)&p->d_lap, lap.size() * sizeof(double)), "hipMalloc(dct lap)");
+    ck(hipMemcpy(p->d_mat, m.data(), m.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(dct matrix)");
+    ck(hipMemcpy(p->d_lap, lap.data(), lap.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(dct lap)");
+    p->n = n;
+    t.plans.push_back(std::move(p));
+    return *t.plans.back();
+}
+const double *get_lap_y(DctTables &t, int h) {   // ftLapY = -4 + 2 cos(pi y/(h-1)) (:187-189)
+    for (auto &l : t.lap_y) if (l.first == h) return l.second;
+    std::vector<double> ly(h);
+    for (int y = 0; y < h; y++) ly[y] = -4.0 + (2.0 * std::cos(M_PI * y / (h - 1)));
+    double *d = nullptr;
+    ck(hipMalloc((void **)&d, h * sizeof(double)), "hipMalloc(lap_y)");
+    ck(hipMemcpy(d, ly.data(), h * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(lap_y)");
+    t.lap_y.push_back({h, d});
+    return d;
 }
 
-PoissonResult poisson_dct(int w, int h, const double *d_c, const double *d_gx, const double *d_gy, double alpha,
-                          double *d_out, hipStream_t stream) {
-    int dev = 0;
-    ck(hipGetDevice(&dev), "hipGetDevice");
-    DctWorkspace &ws = g_dct;
-    if (ws.device != dev) { ws.release(); ws.device = dev; }
+// Enqueue-only unless `timed`: no event is created, recorded or waited for on the product path (stats == NULL).
+PoissonResult poisson_dct(int dev, DctWorkspace &ws, int w, int h, const double *d_c, const double *d_gx, const double *d_gy, double alpha,
+                          double *d_out, hipStream_t stream, bool timed) {
     if (!ws.handle) rb(rocblas_create_handle(&ws.handle), "rocblas_create_handle");
     rb(rocblas_set_stream(ws.handle, stream), "rocblas_set_stream");
-    build_plan(ws.plans[0], w);
-    build_plan(ws.plans[1], h);
+    const double *Cw, *Ch, *lap_x, *lap_y;
+    {
+        DctTables &t = device_tables(dev);
+        std::lock_guard<std::mutex> lk(t.mu);
+        const DctPlan &pw = get_plan(t, w);
+        Cw = pw.d_mat; lap_x = pw.d_lap;
+        Ch = get_plan(t, h).d_mat;
+        lap_y = get_lap_y(t, h);
+    }
     gp::Geo g{w, h, w * h * 3, w * 3};
     const size_t plane = (size_t)w * h;
     if (ws.elems < 3 * plane) {
+        if (ws.buf[0]) ck(hipStreamSynchronize(stream), "hipStreamSynchronize");   // earlier solves may still use the old buffers
         for (auto &b : ws.buf) { if (b) hipFree(b); b = nullptr; }
         for (auto &b : ws.buf) ck(hipMalloc((void **)&b, 3 * plane * sizeof(double)), "hipMalloc(dct buffers)");
         ws.elems = 3 * plane;
     }
     if (!ws.partials) ck(hipMalloc((void **)&ws.partials, 3 * gp::kMaxBlocks * sizeof(double)), "hipMalloc(dct partials)");
-    if (ws.lap_y_n != h) {   // ftLapY = -4 + 2 cos(pi y/(h-1)) (:187-189)
-        if (ws.lap_y) hipFree(ws.lap_y);
-        std::vector<double> ly(h);
-        for (int y = 0; y < h; y++) ly[y] = -4.0 + (2.0 * std::cos(M_PI * y / (h - 1)));
-        ck(hipMalloc((void **)&ws.lap_y, h * sizeof(double)), "hipMalloc(lap_y)");
-        ck(hipMemcpy(ws.lap_y, ly.data(), h * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(lap_y)");
-        ws.lap_y_n = h;
-    }
     const int nb = std::min(gp::kMaxBlocks, (g.n3 + gp::kBlock - 1) / gp::kBlock);
-    hipEvent_t e0, e1;
-    ck(hipEventCreate(&e0), "hipEventCreate"); ck(hipEventCreate(&e1), "hipEventCreate");
-    ck(hipEventRecord(e0, stream), "hipEventRecord");
+    if (timed) {
+        for (auto &e : ws.ev) if (!e) ck(hipEventCreate(&e), "hipEventCreate");
+        ck(hipEventRecord(ws.ev[0], stream), "hipEventRecord");
+    }
     double *A = ws.buf[0], *B = ws.buf[1];
     hipLaunchKernelGGL(gp::dct_rhs_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, alpha, d_c, d_gx, d_gy, A, ws.partials);
     const double one = 1.0, zero = 0.0;
-    const double *Cw = ws.plans[0].d_mat, *Ch = ws.plans[1].d_mat;
     // Row-major X (h x w) is the column-major matrix X^T (w x h, ld = w). Row transform T = X * Cw  <=>  T^T = Cw^T * X^T:
     // the row-major buffer of Cw read column-major IS Cw^T, so (N, N). Column transform Y = Ch^T * T  <=>  Y^T = T^T * Ch:
     // the buffer of Ch read column-major is Ch^T, hence op = T on it.
@@ -396,16 +433,17 @@ PoissonResult poisson_dct(int w, int h, const double *d_c, const double *d_gx, c
                                          tmp, w, (rocblas_stride)plane, Ch, h, 0, &zero, dst, w, (rocblas_stride)plane, 3), "dgemm(cols)");
     };
     transform(A, B, A);                                      // A = DCT2D(h)
-    hipLaunchKernelGGL(gp::dct_scale_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, alpha, ws.plans[0].d_lap, ws.lap_y, A);
+    hipLaunchKernelGGL(gp::dct_scale_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, alpha, lap_x, lap_y, A);
     hipLaunchKernelGGL(gp::dct_dc_kernel, dim3(1), dim3(gp::kBlock), 0, stream, g, A, ws.partials, nb);
     transform(A, B, A);                                      // A = DCT2D(F^)
     hipLaunchKernelGGL(gp::dct_finalize_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, A, d_out);
     ck(hipGetLastError(), "dct kernel launch");
-    ck(hipEventRecord(e1, stream), "hipEventRecord");
-    ck(hipEventSynchronize(e1), "hipEventSynchronize");
     float ms = 0;
-    ck(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (timed) {
+        ck(hipEventRecord(ws.ev[1], stream), "hipEventRecord");
+        ck(hipEventSynchronize(ws.ev[1]), "hipEventSynchronize");
+        ck(hipEventElapsedTime(&ms, ws.ev[0], ws.ev[1]), "hipEventElapsedTime");
+    }
     PoissonResult res;
     res.iterations = 0; res.solver = GDPT_SOLVER_DCT; res.rel_residual = 0.0; res.solve_ms = ms;
     return res;
@@ -414,9 +452,13 @@ PoissonResult poisson_dct(int w, int h, const double *d_c, const double *d_gx, c
 } // namespace
 
 void poisson_release_workspace() {
-    std::lock_guard<std::mutex> lk(g_ws_mu);
-    g_ws.release();
-    g_dct.release();
+    std::lock_guard<std::mutex> lk(g_registry_mu);
+    int cur = 0;
+    hipGetDevice(&cur);
+    for (auto &kv : g_streams) { hipSetDevice(kv.first.first); kv.second->cg.release(); kv.second->dct.release(); }
+    for (auto &kv : g_tables) { hipSetDevice(kv.first); kv.second->release(); }
+    g_streams.clear(); g_tables.clear();
+    hipSetDevice(cur);
 }
 
 void launch_assemble(int w, int h, const double *img, const double *cx0, const double *cy0, const double *cx1, const double *cy1,
@@ -429,22 +471,25 @@ void launch_assemble(int w, int h, const double *img, const double *cx0, const d
 }
 
 PoissonResult poisson_solve_device(int w, int h, const double *d_c, const double *d_gx, const double *d_gy, double alpha,
-                                   double *d_out, int solver, double tol, int max_iters, hipStream_t stream) {
+                                   double *d_out, int solver, double tol, int max_iters, hipStream_t stream, bool timed) {
     if (w < 2 || h < 2) throw std::runtime_error("poisson: width and height must be >= 2 (the reference divides by (W-1)(H-1))");
     if (!(alpha > 0)) throw std::runtime_error("poisson: dataCost must be > 0");
     if (solver != GDPT_SOLVER_CG && solver != GDPT_SOLVER_DCT) throw std::runtime_error("poisson: unknown solver");
     if (tol <= 0) tol = 1e-10;
     if (max_iters <= 0) max_iters = 2000;
-    std::lock_guard<std::mutex> lk(g_ws_mu);
-    if (solver == GDPT_SOLVER_DCT) return poisson_dct(w, h, d_c, d_gx, d_gy, alpha, d_out, stream);
+    int dev = 0;
+    ck(hipGetDevice(&dev), "hipGetDevice");
+    StreamState &ss = stream_state(dev, stream);
+    std::lock_guard<std::mutex> lk(ss.mu);
+    if (solver == GDPT_SOLVER_DCT) return poisson_dct(dev, ss.dct, w, h, d_c, d_gx, d_gy, alpha, d_out, stream, timed);
     gp::Geo g{w, h, w * h * 3, w * 3};
-    g_ws.ensure((size_t)g.n3);
-    Workspace &ws = g_ws;
+    if ((size_t)g.n3 > ss.cg.n3 && ss.cg.n3) ck(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    ss.cg.ensure((size_t)g.n3);
+    Workspace &ws = ss.cg;
     const int nb = std::min(gp::kMaxBlocks, (g.n3 + gp::kBlock - 1) / gp::kBlock);
     // init layout: 8 slots of nb doubles (slot 0 = <r,r>, reused as part_rr); <p,q> partials live in slot 8
     double *part_rr = ws.partials, *part_pq = ws.partials + 8 * (size_t)nb;
-    hipEvent_t e0, e1;
-    ck(hipEventCreate(&e0), "hipEventCreate"); ck(hipEventCreate(&e1), "hipEventCreate");
+    hipEvent_t e0 = ws.ev[0], e1 = ws.ev[1];
     ck(hipEventRecord(e0, stream), "hipEventRecord");
     hipLaunchKernelGGL(gp::cg_init_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, alpha, d_c, d_gx, d_gy, ws.x, ws.r, ws.p0, ws.p1, ws.partials);
     hipLaunchKernelGGL(gp::cg_init_reduce_kernel, dim3(1), dim3(gp::kBlock), 0, stream, nb, ws.partials, ws.state, tol);
@@ -464,8 +509,7 @@ PoissonResult poisson_solve_device(int w, int h, const double *d_c, const double
         launched += chunk;
         ck(hipGetLastError(), "cg chunk launch");
     };
-    hipEvent_t chunk_ev;
-    ck(hipEventCreate(&chunk_ev), "hipEventCreate");
+    hipEvent_t chunk_ev = ws.ev[2];
     enqueue_chunk();
     while (!done) {
         ck(hipMemcpyAsync(ws.h_state, ws.state, sizeof(gp::CgState), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(state)");
@@ -483,7 +527,6 @@ PoissonResult poisson_solve_device(int w, int h, const double *d_c, const double
     ck(hipEventSynchronize(e1), "hipEventSynchronize");
     float ms = 0;
     ck(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
-    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(chunk_ev);
     PoissonResult res;
     res.iterations = ws.h_state->iters; res.solver = GDPT_SOLVER_CG; res.rel_residual = *ws.h_rel; res.solve_ms = ms;
     return res;

@@ -1,6 +1,7 @@
 // bvh.cpp — binned-SAH BVH2 with a hard depth bound (so the GPU traversal stack, one LDS slot
 // per level per lane, can never overflow).
 #include "bvh.h"
+#include "../capi_common.h"
 
 #include <cstdlib>
 #include <algorithm>
@@ -160,8 +161,9 @@ struct Builder {
 
 BvhBuildResult build_bvh(const std::vector<PrimBounds> &bounds) {
     Builder bld(bounds);
-    if (const char *v = std::getenv("GDPT_BVH_LEAF_MAX")) bld.leaf_max = (uint32_t)std::min(std::max(std::atoi(v), 1), GDPT_LEAF_MAX_PRIMS);
-    if (const char *v = std::getenv("GDPT_BVH_LEAF_FACTOR")) bld.leaf_factor = (float)std::atof(v);
+    // leaf policy overrides of the tree-independence test (include/gdpt_debug.h); defaults = the product path
+    bld.leaf_max = (uint32_t)std::min(std::max(debug_knob_int("bvh_leaf_max", (int)bld.leaf_max), 1), GDPT_LEAF_MAX_PRIMS);
+    bld.leaf_factor = (float)debug_knob("bvh_leaf_factor", (double)bld.leaf_factor);
     uint32_t n = (uint32_t)bounds.size();
     if (n == 0) return std::move(bld.out);
     bld.idx.resize(n);

@@ -1,5 +1,6 @@
 // presplit.cpp — early split clipping of large triangles ahead of the SAH build (see bvh.h).
 #include "bvh.h"
+#include "../capi_common.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -78,8 +79,7 @@ void presplit_triangles(const std::vector<PrimBounds> &bounds, const std::vector
     for (int k = 0; k < 3; k++) { slo[k] = std::numeric_limits<float>::infinity(); shi[k] = -slo[k]; }
     for (const PrimBounds &b : bounds) for (int k = 0; k < 3; k++) { slo[k] = std::min(slo[k], b.bmin[k]); shi[k] = std::max(shi[k], b.bmax[k]); }
     // boxes below this size are left alone however much budget is left
-    float floor_key = half_area(slo, shi) * 1e-6f;
-    if (const char *e = std::getenv("GDPT_PRESPLIT_FLOOR")) floor_key = half_area(slo, shi) * (float)std::atof(e);
+    const float floor_key = half_area(slo, shi) * (float)debug_knob("presplit_floor", 1e-6);
 
     // candidates: the (budget-limited) largest triangle boxes
     std::vector<Ref *> pool;

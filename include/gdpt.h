@@ -204,7 +204,11 @@ int gdpt_render(GdptScene *scene, const GdptRenderParams *params,
 
 /* ---- hot path, device buffers (hipMalloc'd / torch CUDA tensors; data stays in HBM) ----
  * `stream` is a hipStream_t passed as void* (NULL = default stream). Asynchronous w.r.t. the host
- * unless `stats` is non-NULL (then it synchronises to read the counters). */
+ * unless `stats` is non-NULL (then it synchronises to read the counters).
+ * A GdptScene owns ONE set of launch scratch (work queue, per-item partial sums, counters, bounce log): at most one
+ * render of a given scene handle may be in flight at a time. Renders issued on the same stream are ordered by it;
+ * to overlap renders on different streams (or devices) upload one scene handle per stream — the scene tables are
+ * a few MB. The reference's render() is likewise called once, synchronously (src/main.cpp:40). */
 int gdpt_render_device(GdptScene *scene, const GdptRenderParams *params,
                        double *d_img, double *d_cx0, double *d_cy0, double *d_cx1, double *d_cy1,
                        void *stream, GdptRenderStats *stats /* nullable */);
@@ -234,7 +238,9 @@ int gdpt_poisson_solve_ex(int width, int height,
                           const double *imgData, const double *imgGradX, const double *imgGradY,
                           double dataCost, double *imgOut,
                           int solver, double tol, int max_iters, GdptPoissonStats *stats /* nullable */);
-/* Device-pointer variant (inputs/outputs in HBM). `workspace` may be NULL (the library keeps a cached one). */
+/* Device-pointer variant (inputs/outputs in HBM). The library keeps its scratch per (device, stream). With
+ * GDPT_SOLVER_DCT and stats == NULL the call only enqueues work on `stream` (no event, no host wait); with stats it
+ * brackets the solve with HIP events and waits for it. GDPT_SOLVER_CG always waits (host-side convergence check). */
 int gdpt_poisson_solve_device(int width, int height,
                               const double *d_c, const double *d_gx, const double *d_gy,
                               double dataCost, double *d_out,

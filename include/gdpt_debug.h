@@ -1,0 +1,39 @@
+/* gdpt_debug.h — test instrument, NOT part of the drop-in boundary of include/gdpt.h.
+ *
+ * The product entry points take every scheduling decision (which evaluator, how a pixel's samples are cut into work
+ * items, whether a small scene is copied to LDS, BVH leaf policy ...) from the scene and the render parameters alone;
+ * no environment variable is read anywhere in libgdpt.so. The parity tests, however, must be able to force the
+ * alternatives (straight-loop evaluator vs lane machine, 1 / 2 / 8 work items per pixel, HBM walk of an LDS-sized
+ * scene, a second BVH over the same triangles) to show that they agree. These two calls are that switchboard: a
+ * process-global table of overrides, empty unless a test fills it. Nothing in lajolla, bench.py's timed region or the
+ * library itself calls them.
+ *
+ * Knob names (value semantics in parentheses; an unknown name is an error):
+ *   force_eager          (0/1)  straight per-sample loop instead of the lane machine
+ *   log2k                (int)  work items (or lanes) per pixel = 2^value
+ *   keep_frac            (0..255) trace phase is left when this fraction /256 of its rays is unfinished
+ *   search_frac          (0..255) node loop is left when this fraction /256 of the live lanes still searches a leaf
+ *   blocks_per_cu        (int)  persistent blocks per compute unit
+ *   no_lds_scene         (0/1)  walk an LDS-sized scene from HBM
+ *   lds_wide             (0/1)  LDS-resident scenes in BVH4 form (default 1)
+ *   no_twosided_machine  (0/1)  two-sided lobes on the straight loop instead of the replay machine
+ *   presplit             (real) triangle pre-split budget, extra references per primitive (scene upload)
+ *   presplit_floor       (real) pre-split priority floor (scene upload)
+ *   bvh_leaf_max         (1..4) SAH builder: primitives per leaf (scene upload)
+ *   bvh_leaf_factor      (real) SAH builder: leaf cost factor (scene upload)
+ */
+#ifndef GDPT_DEBUG_H
+#define GDPT_DEBUG_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Sets one override; returns 0, or non-zero (message in gdpt_last_error) for an unknown name. */
+int gdpt_debug_knob_set(const char *name, double value);
+/* Removes every override: the library is back on its product path. */
+void gdpt_debug_knobs_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDPT_DEBUG_H */

@@ -1,4 +1,4 @@
-"""Manual sweep of the BVH leaf policy knobs (GDPT_BVH_LEAF_MAX / GDPT_BVH_LEAF_FACTOR) on one GPU (not collected by pytest)."""
+"""Manual sweep of the BVH leaf policy knobs (debug knobs bvh_leaf_max / bvh_leaf_factor, include/gdpt_debug.h) on one GPU (not collected by pytest)."""
 import os, sys, tempfile, itertools
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,7 +8,7 @@ tmp = tempfile.mkdtemp()
 cases = [("cbox", "cbox/cbox_gdpt.xml", 512, 512, None, 64), ("sponza", "sponza/sponza.xml", 1280, 720, None, 16),
          ("disney_metal", "disney_bsdf_test/disney_metal.xml", 512, 512, "gradpath", 16)]
 for lm, lf in [(4, 1.0), (4, 0.8), (2, 0.8), (4, 0.8), (4, 1.0), (2, 1.0), (4, 0.8)]:
-    os.environ["GDPT_BVH_LEAF_MAX"] = str(lm); os.environ["GDPT_BVH_LEAF_FACTOR"] = str(lf)
+    G.debug_knobs.reset(); G.debug_knobs.set(bvh_leaf_max=lm, bvh_leaf_factor=lf)
     row = []
     for name, rel, w, h, integ, spp in cases:
         xml = scene_variant(tmp, rel, width=w, height=h, integrator=integ)

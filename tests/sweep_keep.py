@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import gdpt_amd as G
+    G.debug_knobs.from_env()      # the parent passes GDPT_KEEP_FRAC / GDPT_SEARCH_FRAC; the library itself reads no environment
     from helpers import scene_variant
     out = {}
     for name, xml, spp in (("cbox", os.path.join(ROOT, "scenes/cbox/cbox_gdpt.xml"), 16),

@@ -1,4 +1,4 @@
-"""Manual sweep of the triangle pre-split budget (GDPT_PRESPLIT) on one GPU (not collected by pytest)."""
+"""Manual sweep of the triangle pre-split budget (debug knob presplit, include/gdpt_debug.h) on one GPU (not collected by pytest)."""
 import os, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,8 +10,7 @@ cases = [("sponza", "sponza/sponza.xml", 1280, 720, None, 16), ("disney_metal", 
          ("veach_mi", "veach_mi/mi.xml", 768, 512, "gradpath", 16)]
 ref = {}
 for budget, floor in ((0.0, 1e-6), (0.0, 1e-6), (0.3, 1e-6), (1.0, 1e-6), (1.0, 1e-5), (1.0, 1e-4), (3.0, 1e-5), (3.0, 1e-6)):
-    os.environ["GDPT_PRESPLIT_FLOOR"] = str(floor)
-    os.environ["GDPT_PRESPLIT"] = str(budget)
+    G.debug_knobs.reset(); G.debug_knobs.set(presplit_floor=floor, presplit=budget)
     row = []
     for name, rel, w, h, integ, spp in cases:
         xml = scene_variant(tmp, rel, width=w, height=h, integrator=integ)

@@ -9,9 +9,14 @@ from helpers import ROOT
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "gdpt.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(gdpt_[a-z_]+)\s*\(", text)))
+    names = set()
+    for header in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if not header.endswith(".h"):
+            continue
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(gdpt_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol(G):
@@ -69,3 +74,24 @@ def test_product_code_never_touches_the_oracle():
     assert not offenders, offenders
     cli = open(os.path.join(pkg, "csrc", "lajolla_main.cpp")).read()
     assert "oracle" not in cli
+
+
+def test_no_environment_variable_reaches_the_kernels(G):
+    """Scheduling overrides exist only as the test-only table of include/gdpt_debug.h: nothing under the package reads
+    the process environment (a stray GDPT_* variable must not change what the benchmark times), and an unknown knob is
+    an error rather than a silent no-op."""
+    pkg = os.path.join(ROOT, "gradient-based-path-tracing_amd", "csrc")
+    offenders = []
+    for dp, dn, files in os.walk(pkg):
+        if os.path.basename(dp) == "build":
+            continue
+        for f in files:
+            if f.endswith((".cpp", ".h", ".hip")) and re.search(r"\bgetenv\b|\benviron\b", open(os.path.join(dp, f), errors="ignore").read()):
+                offenders.append(f)
+    assert not offenders, offenders
+    import pytest
+    with pytest.raises(G.GdptError):
+        G.debug_knobs.set(no_such_knob=1)
+    with G.debug_knobs(log2k=2, presplit=0.5):
+        pass
+    G.debug_knobs.reset()

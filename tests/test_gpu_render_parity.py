@@ -54,12 +54,9 @@ def test_work_item_granularity_does_not_change_the_result(G, scene_tmp, monkeypa
     xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=40, height=24)
     sc = G.Scene(G.parse_scene(xml))
     ref, rst = sc.render(16, G.RNG_SAMPLE)
-    for env in ({"GDPT_LOG2K": "0"}, {"GDPT_LOG2K": "1"}, {"GDPT_LOG2K": "3"}, {"GDPT_FORCE_EAGER": "1"}, {"GDPT_NO_LDS_SCENE": "1"}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        got, st = sc.render(16, G.RNG_SAMPLE)
-        for k in env:
-            monkeypatch.delenv(k)
+    for env in ({"log2k": 0}, {"log2k": 1}, {"log2k": 3}, {"force_eager": 1}, {"no_lds_scene": 1}):
+        with G.debug_knobs(**env):
+            got, st = sc.render(16, G.RNG_SAMPLE)
         assert st.bounces == rst.bounces
         for k in BUFS:
             assert rel_l2(got[k], ref[k]) < 1e-12, (env, k)
@@ -256,9 +253,8 @@ def test_two_sided_lane_machine_replays_offsets_exactly(G, O, scene_tmp, scene, 
     sd = G.parse_scene(xml)
     sc = G.Scene(sd)
     got, st = sc.render(6, G.RNG_SAMPLE)
-    monkeypatch.setenv("GDPT_NO_TWOSIDED_MACHINE", "1")
-    eager, est = sc.render(6, G.RNG_SAMPLE)
-    monkeypatch.delenv("GDPT_NO_TWOSIDED_MACHINE")
+    with G.debug_knobs(no_twosided_machine=1):
+        eager, est = sc.render(6, G.RNG_SAMPLE)
     want, ost = O.OracleScene(sd.ptr, use_bvh=True).render(6, G.RNG_SAMPLE, threads=8)
     for k in BUFS:
         assert rel_l2(got[k], eager[k]) < 1e-12, k
@@ -278,9 +274,8 @@ def test_closest_hit_does_not_depend_on_the_tree(G, scene_tmp, rel, integ, monke
     xml = scene_variant(scene_tmp, rel, width=160, height=96, integrator=integ)
     sd = G.parse_scene(xml)
     a, sa = G.Scene(sd).render(4, G.RNG_SAMPLE)
-    monkeypatch.setenv("GDPT_PRESPLIT", "0.7")
-    monkeypatch.setenv("GDPT_BVH_LEAF_MAX", "2")
-    b, sb = G.Scene(sd).render(4, G.RNG_SAMPLE)
+    with G.debug_knobs(presplit=0.7, bvh_leaf_max=2):
+        b, sb = G.Scene(sd).render(4, G.RNG_SAMPLE)
     for k in BUFS:
         assert np.array_equal(np.asarray(a[k]), np.asarray(b[k]), equal_nan=True), k
     assert sa.rays == sb.rays and sa.bounces == sb.bounces

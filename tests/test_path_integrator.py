@@ -154,12 +154,9 @@ def test_gpu_path_persistent_and_straight_loop_agree(G, scene_tmp, monkeypatch):
     xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=40, height=24, integrator="path")
     sc = G.Scene(G.parse_scene(xml))
     ref, rst = sc.path_render(16, G.RNG_SAMPLE)
-    for env in ({"GDPT_FORCE_EAGER": "1"}, {"GDPT_NO_LDS_SCENE": "1"}, {"GDPT_LOG2K": "0"}, {"GDPT_KEEP_FRAC": "0", "GDPT_SEARCH_FRAC": "0"}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        got, st = sc.path_render(16, G.RNG_SAMPLE)
-        for k in env:
-            monkeypatch.delenv(k)
+    for env in ({"force_eager": 1}, {"no_lds_scene": 1}, {"log2k": 0}, {"keep_frac": 0, "search_frac": 0}):
+        with G.debug_knobs(**env):
+            got, st = sc.path_render(16, G.RNG_SAMPLE)
         assert rel_l2(got, ref) < 1e-12 and st.bounces == rst.bounces, env
 
 

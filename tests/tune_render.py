@@ -5,6 +5,7 @@ code = r'''
 import sys, os
 sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests"); sys.path.insert(0, %r + "/oracle")
 import gdpt_amd as G, numpy as np
+G.debug_knobs.from_env()      # GDPT_* of the parent -> test-only overrides (the library reads no environment)
 sd = G.parse_scene(%r + "/scenes/cbox/cbox_gdpt.xml"); sc = G.Scene(sd)
 ms = []
 for i in range(4):
