@@ -47,6 +47,7 @@ def lib():
         L.gdpt_last_error.restype = C.c_char_p
         L.gdpt_build_arch.restype = C.c_char_p
         L.gdpt_parse_scene.argtypes = [C.c_char_p, C.POINTER(C.POINTER(defs.GdptSceneDesc))]
+        L.gdpt_parse_scene_film.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.POINTER(defs.GdptSceneDesc))]
         L.gdpt_free_scene_desc.argtypes = [C.POINTER(defs.GdptSceneDesc)]
         L.gdpt_scene_upload.argtypes = [C.POINTER(defs.GdptSceneDesc), C.c_int, C.POINTER(vp)]
         L.gdpt_scene_free.argtypes = [vp]
@@ -67,6 +68,13 @@ def lib():
         L.gdpt_imread.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(dp)]
         L.gdpt_image_free.argtypes = [dp]
         L.gdpt_bvh_check.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int32)]
+        L.gdpt_assemble_rows_device.argtypes = [C.c_int] * 4 + [vp] * 9
+        L.gdpt_band_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.gdpt_multi_create.argtypes = [C.POINTER(defs.GdptSceneDesc), C.POINTER(defs.GdptMultiConfig), C.POINTER(vp)]
+        L.gdpt_multi_free.argtypes = [vp]
+        L.gdpt_multi_free.restype = None
+        L.gdpt_multi_gradient_path_render.argtypes = [vp, C.POINTER(defs.GdptRenderParams), C.c_double, dp, dp, dp, dp, dp, dp,
+                                                      C.POINTER(defs.GdptRenderStats), C.POINTER(defs.GdptMultiStats)]
         L.gdpt_debug_knob_set.argtypes = [C.c_char_p, C.c_double]
         L.gdpt_debug_knobs_reset.restype = None
         _LIB = L
@@ -112,10 +120,11 @@ class SceneDesc:
             pass
 
 
-def parse_scene(filename):
-    """Mitsuba-0.x XML subset -> SceneDesc (reference: parse_scene, src/parsers/parse_scene.cpp:1615-1630)."""
+def parse_scene(filename, film=(0, 0)):
+    """Mitsuba-0.x XML subset -> SceneDesc (reference: parse_scene, src/parsers/parse_scene.cpp:1615-1630).
+    `film` = (width, height) replaces the <film> extent of the file (0 keeps it)."""
     p = C.POINTER(defs.GdptSceneDesc)()
-    _check(lib().gdpt_parse_scene(os.fsencode(filename), C.byref(p)))
+    _check(lib().gdpt_parse_scene_film(os.fsencode(filename), int(film[0]), int(film[1]), C.byref(p)))
     return SceneDesc(p)
 
 
@@ -215,9 +224,56 @@ def fourierSolve(width, height, imgData, imgGradX, imgGradY, dataCost=0.04, solv
     return (out, st) if return_stats else out
 
 
-def assemble_device(width, height, src_ptrs, dst_ptrs, stream=None):
-    _check(lib().gdpt_assemble_device(int(width), int(height), *[C.c_void_p(int(x)) for x in src_ptrs],
-                                      *[C.c_void_p(int(x)) for x in dst_ptrs], C.c_void_p(int(stream) if stream else 0)))
+def assemble_device(width, height, src_ptrs, dst_ptrs, stream=None, rows=(0, 0)):
+    """c, cx, cy from the five accumulation buffers (src/render.cpp:340-350); `rows` = the band this rank owns."""
+    _check(lib().gdpt_assemble_rows_device(int(width), int(height), int(rows[0]), int(rows[1]),
+                                           *[C.c_void_p(int(x)) for x in src_ptrs],
+                                           *[C.c_void_p(int(x)) for x in dst_ptrs], C.c_void_p(int(stream) if stream else 0)))
+
+
+def band_rows(height, num_bands, band):
+    """Rows [r0, r1) of one band of the sharded tile loop, as the C host computes them (gdpt_band_rows)."""
+    r0, r1 = C.c_int32(), C.c_int32()
+    _check(lib().gdpt_band_rows(int(height), int(num_bands), int(band), C.byref(r0), C.byref(r1)))
+    return r0.value, r1.value
+
+
+class MultiScene:
+    """The scene uploaded to several devices of one node, tile loop sharded into row bands (include/gdpt.h,
+    gdpt_multi_*): replaces the reference's thread pool over tiles (src/parallel.cpp:183-256)."""
+
+    def __init__(self, scene_desc, devices, exchange=defs.EXCHANGE_RCCL):
+        self.desc = scene_desc
+        self.width, self.height = scene_desc.width, scene_desc.height
+        cfg = defs.GdptMultiConfig()
+        cfg.num_devices, cfg.exchange = len(devices), int(exchange)
+        for i, d in enumerate(devices):
+            cfg.devices[i] = int(d)
+        h = C.c_void_p()
+        _check(lib().gdpt_multi_create(scene_desc.ptr, C.byref(cfg), C.byref(h)))
+        self.handle = h
+
+    def gradient_path_render(self, spp=0, rng_scheme=defs.RNG_SAMPLE, alpha=0.04, return_buffers=False, shift=defs.SHIFT_REFERENCE):
+        shape = (self.height, self.width, 3)
+        out = np.zeros(shape, dtype=np.float64)
+        bufs = {k: np.zeros(shape, dtype=np.float64) for k in ("img", "cx0", "cy0", "cx1", "cy1")}
+        rs, ms = defs.GdptRenderStats(), defs.GdptMultiStats()
+        p = _params(spp, rng_scheme, (0, 0), shift=shift)
+        _check(lib().gdpt_multi_gradient_path_render(self.handle, C.byref(p), float(alpha), _dp(out),
+                                                     _dp(bufs["img"]), _dp(bufs["cx0"]), _dp(bufs["cy0"]), _dp(bufs["cx1"]), _dp(bufs["cy1"]),
+                                                     C.byref(rs), C.byref(ms)))
+        return (out, bufs, rs, ms) if return_buffers else out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().gdpt_multi_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def poisson_solve_device(width, height, c_ptr, gx_ptr, gy_ptr, out_ptr, alpha=0.04, solver=defs.SOLVER_DCT, tol=0.0,

@@ -79,3 +79,18 @@ class GdptRenderStats(C.Structure):
 
 class GdptPoissonStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("solver", C.c_int32), ("rel_residual", C.c_double), ("solve_ms", C.c_double)]
+
+
+GDPT_MULTI_MAX_DEVICES = 16
+EXCHANGE_RCCL, EXCHANGE_PEER_COPY = 0, 1
+
+
+class GdptMultiConfig(C.Structure):
+    _fields_ = [("num_devices", C.c_int32), ("exchange", C.c_int32), ("devices", C.c_int32 * GDPT_MULTI_MAX_DEVICES)]
+
+
+class GdptMultiStats(C.Structure):
+    _fields_ = [("num_devices", C.c_int32), ("exchange", C.c_int32),
+                ("row_begin", C.c_int32 * GDPT_MULTI_MAX_DEVICES), ("row_end", C.c_int32 * GDPT_MULTI_MAX_DEVICES),
+                ("render_ms", C.c_double * GDPT_MULTI_MAX_DEVICES), ("render_ms_max", C.c_double),
+                ("exchange_ms", C.c_double), ("solve_ms", C.c_double), ("wall_ms", C.c_double)]

@@ -59,10 +59,13 @@ void gdpt_debug_knobs_reset(void) {
     gdpt::g_knobs.clear();
 }
 
-int gdpt_parse_scene(const char *xml_path, GdptSceneDesc **out_desc) {
+int gdpt_parse_scene(const char *xml_path, GdptSceneDesc **out_desc) { return gdpt_parse_scene_film(xml_path, 0, 0, out_desc); }
+
+int gdpt_parse_scene_film(const char *xml_path, int film_width, int film_height, GdptSceneDesc **out_desc) {
     return gdpt::guarded([&]() {
         if (!xml_path || !out_desc) throw std::runtime_error("gdpt_parse_scene: null argument");
-        std::unique_ptr<gdpt::HostScene> hs = gdpt::load_scene_xml(xml_path);
+        if (film_width < 0 || film_height < 0 || film_width > 65536 || film_height > 65536) throw std::runtime_error("gdpt_parse_scene_film: bad film extent");
+        std::unique_ptr<gdpt::HostScene> hs = gdpt::load_scene_xml(xml_path, film_width, film_height);
         GdptSceneDesc *d = &hs->desc;
         std::lock_guard<std::mutex> lk(g_mu);
         g_descs[d] = std::move(hs);

@@ -7,6 +7,7 @@
 #include "../host/tri_precompute.h"
 #include "poisson_kernels.h"
 #include "render_kernels.h"
+#include "scene_internal.h"
 
 #include <hip/hip_runtime.h>
 
@@ -21,9 +22,7 @@
 
 namespace {
 
-void ck(hipError_t e, const char *what) {
-    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
-}
+using gdpt::ck;
 
 template <class T>
 T *upload(const std::vector<T> &v) {
@@ -38,51 +37,7 @@ T *upload(const std::vector<T> &v) {
 
 static constexpr double kPresplitBudget = 0.0;   // extra references / primitives (GDPT_PRESPLIT overrides)
 
-struct GdptScene {
-    int device = 0;
-    DevSceneView view{};
-    int bvh_depth = 0;
-    int wide_stack_need = 0;
-    bool has_envmap = false;
-    int scene_spp = 0;             // <sampler sampleCount> of the description (default spp)
-    bool one_sided = true, lambert_only = true;
-    bool has_rough = false;        // RoughPlastic / RoughDielectric present: GradPath uses the evaluator built with those lobes
-    std::vector<void *> allocations;
-    // cached output/work buffers for the host-pointer entry points
-    double *d_buf[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t buf_elems = 0;
-    gdpt::RenderCounters *d_counters = nullptr;
-    gdpt::RenderCounters *h_counters = nullptr; // pinned
-    void *d_bounce_log = nullptr; size_t bounce_log_bytes = 0;   // per-lane bounce log of the two-sided lane machine
-    double *d_partials = nullptr; size_t partials_doubles = 0;   // work-item partial sums of the persistent render kernel
-    unsigned long long *d_queue = nullptr;
-    int num_cus = 256;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-
-    template <class T>
-    T *keep(T *p) { if (p) allocations.push_back((void *)p); return p; }
-
-    void ensure_buffers(size_t elems) {
-        if (elems <= buf_elems) return;
-        for (auto &b : d_buf) { if (b) hipFree(b); b = nullptr; }
-        for (auto &b : d_buf) ck(hipMalloc((void **)&b, elems * sizeof(double)), "hipMalloc(image buffers)");
-        buf_elems = elems;
-    }
-    ~GdptScene() {
-        hipSetDevice(device);
-        for (void *p : allocations) hipFree(p);
-        for (auto &b : d_buf) if (b) hipFree(b);
-        if (d_counters) hipFree(d_counters);
-        if (d_partials) hipFree(d_partials);
-        if (d_bounce_log) hipFree(d_bounce_log);
-        if (d_queue) hipFree(d_queue);
-        if (h_counters) hipHostFree(h_counters);
-        if (ev0) hipEventDestroy(ev0);
-        if (ev1) hipEventDestroy(ev1);
-    }
-};
-
-namespace {
+namespace gdpt {
 
 void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     if (!desc) throw std::runtime_error("gdpt_scene_upload: null scene description");
@@ -415,6 +370,12 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     ck(hipEventCreate(&sc->ev1), "hipEventCreate");
 }
 
+} // namespace gdpt
+
+namespace {
+
+using gdpt::build_scene;
+
 struct Band { int spp, rng, row_begin, row_end, max_depth, shift; };
 
 Band resolve(const GdptScene *sc, const GdptRenderParams *p) {
@@ -436,6 +397,9 @@ Band resolve(const GdptScene *sc, const GdptRenderParams *p) {
     return b;
 }
 
+} // namespace
+
+namespace gdpt {
 // Enqueues one render; returns after enqueue unless stats are requested.
 void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene_spp,
                         double *img, double *cx0, double *cy0, double *cx1, double *cy1,
@@ -506,6 +470,10 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     }
 }
 
+} // namespace gdpt
+
+namespace {
+using gdpt::render_device_impl;
 // Integrator::Path: enqueues one render of `img`; returns after enqueue unless stats are requested.
 void path_render_device_impl(GdptScene *sc, const GdptRenderParams *params, double *img, hipStream_t stream, GdptRenderStats *stats) {
     ck(hipSetDevice(sc->device), "hipSetDevice");
@@ -641,12 +609,16 @@ int gdpt_path_render(GdptScene *scene, const GdptRenderParams *params, double *i
     });
 }
 
-int gdpt_assemble_device(int width, int height, const double *d_img, const double *d_cx0, const double *d_cy0,
-                         const double *d_cx1, const double *d_cy1, double *d_c, double *d_cx, double *d_cy, void *stream) {
+int gdpt_assemble_rows_device(int width, int height, int row_begin, int row_end, const double *d_img, const double *d_cx0, const double *d_cy0,
+                              const double *d_cx1, const double *d_cy1, double *d_c, double *d_cx, double *d_cy, void *stream) {
     return gdpt::guarded([&]() {
         if (!d_img || !d_cx0 || !d_cy0 || !d_cx1 || !d_cy1 || !d_c || !d_cx || !d_cy) throw std::runtime_error("gdpt_assemble_device: null buffer");
-        gdpt::launch_assemble(width, height, d_img, d_cx0, d_cy0, d_cx1, d_cy1, d_c, d_cx, d_cy, (hipStream_t)stream);
+        gdpt::launch_assemble(width, height, row_begin, row_end, d_img, d_cx0, d_cy0, d_cx1, d_cy1, d_c, d_cx, d_cy, (hipStream_t)stream);
     });
+}
+int gdpt_assemble_device(int width, int height, const double *d_img, const double *d_cx0, const double *d_cy0,
+                         const double *d_cx1, const double *d_cy1, double *d_c, double *d_cx, double *d_cy, void *stream) {
+    return gdpt_assemble_rows_device(width, height, 0, 0, d_img, d_cx0, d_cy0, d_cx1, d_cy1, d_c, d_cx, d_cy, stream);
 }
 
 int gdpt_poisson_solve_device(int width, int height, const double *d_c, const double *d_gx, const double *d_gy,
@@ -702,7 +674,7 @@ int gdpt_gradient_path_render(GdptScene *scene, const GdptRenderParams *params, 
         p.row_begin = 0; p.row_end = 0;   // the solve is global: whole image only
         GdptRenderStats local{};
         render_device_impl(scene, &p, scene->scene_spp, b[0], b[1], b[2], b[3], b[4], nullptr, rstats ? rstats : &local);
-        gdpt::launch_assemble(w, h, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], nullptr);
+        gdpt::launch_assemble(w, h, 0, 0, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], nullptr);
         gdpt::PoissonResult r = gdpt::poisson_solve_device(w, h, b[5], b[6], b[7], dataCost, b[8], GDPT_SOLVER_DCT, 0.0, 0, nullptr, pstats != nullptr);
         if (pstats) { pstats->iterations = r.iterations; pstats->solver = r.solver; pstats->rel_residual = r.rel_residual; pstats->solve_ms = r.solve_ms; }
         ck(hipMemcpy(out_image, b[8], elems * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");

@@ -1,0 +1,354 @@
+// multi_gpu.hip — Integrator::GradPath over several devices of one node, behind the C ABI (gdpt_multi_*).
+//
+// Replaces the reference's only parallelism: parallel_for over 16x16 tiles on a std::thread pool
+// (src/render.cpp:271-277, src/parallel.cpp:183-256). A tile's result depends on nothing but the read-only scene and
+// its RNG streams, so the tile loop shards into contiguous bands of whole tile rows, one band per device
+// (SURVEY.md §8(e)). One host thread per device (the pool's worker, now driving a GPU):
+//
+//   render own band  ->  one-row halo  ->  assemble own band  ->  all-gather of c, cx, cy  ->  solve
+//
+//   * halo: cy(x,y) = cy0(x,y) + cy1(x,y-1) (src/render.cpp:345-349) needs the last cy1 row of the band above: W*24
+//     bytes, point to point, to the next device; cx is band-local.
+//   * all-gather: bands are contiguous row ranges in device order, so each image gathers IN PLACE (a device's band
+//     already sits at its final offset): no packing, no copies. Three images, one group.
+//   * solve: global (the DCT couples every pixel); runs on device 0 of the set, whose result goes to the host.
+//
+// Two transports for the exchange (GdptMultiConfig::exchange):
+//   GDPT_EXCHANGE_RCCL       ncclSend/ncclRecv for the halo, grouped in-place ncclAllGather (equal bands) or grouped
+//                            in-place ncclBroadcast per band (ragged bands), one communicator per device
+//                            (ncclCommInitAll), every device's calls issued by its own host thread.
+//   GDPT_EXCHANGE_PEER_COPY  direct device-to-device copies over xGMI: every device pushes its band into the image
+//                            buffers of every other device (hipMemcpyPeerAsync on its own stream, ordered by events).
+//                            xGMI is a full mesh of point-to-point links, so the N-1 pushes of a device use N-1
+//                            different links at once — the "direct" all-gather SURVEY.md §5 prices at 1/7 of a ring.
+//                            Also the only transport that accepts the same device twice (two bands on one GPU), which
+//                            is how the band / halo / gather indexing is verified on a one-GPU box.
+#include "../../../include/gdpt.h"
+#include "../capi_common.h"
+#include "poisson_kernels.h"
+#include "scene_internal.h"
+
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+using gdpt::ck;
+
+void nk(ncclResult_t r, const char *what) {
+    if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r));
+}
+
+constexpr int kTile = 16;   // src/render.cpp:271
+
+// Rows [r0, r1) of band `b` of `n`: whole tile rows, balanced by tile-row count, in band order (sharding.band_rows).
+void band_rows(int height, int n, int b, int *r0, int *r1) {
+    const int tile_rows = (height + kTile - 1) / kTile;
+    const int base = tile_rows / n, extra = tile_rows % n;
+    const int t0 = b * base + std::min(b, extra);
+    const int t1 = t0 + base + (b < extra ? 1 : 0);
+    *r0 = std::min(t0 * kTile, height);
+    *r1 = std::min(t1 * kTile, height);
+}
+
+// Reusable barrier for the per-device host threads of one call (C++17: no std::barrier).
+class HostBarrier {
+    std::mutex mu; std::condition_variable cv; int n, waiting = 0; unsigned long long generation = 0;
+public:
+    explicit HostBarrier(int n_) : n(n_) {}
+    void arrive_and_wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        const unsigned long long gen = generation;
+        if (++waiting == n) { waiting = 0; generation++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+    }
+};
+
+struct Rank {
+    int device = 0, row_begin = 0, row_end = 0;
+    std::unique_ptr<GdptScene> scene;
+    hipStream_t stream = nullptr;
+    double *buf[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // img cx0 cy0 cx1 cy1 | c cx cy | out
+    hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};  // timing: start, rendered, exchanged, solved
+    hipEvent_t ev_rendered = nullptr, ev_pushed = nullptr;       // peer-copy ordering
+    ncclComm_t comm = nullptr;
+    GdptRenderStats rstats{};
+    std::string error;
+};
+
+} // namespace
+
+struct GdptMulti {
+    int n = 0, w = 0, h = 0, exchange = GDPT_EXCHANGE_RCCL, scene_spp = 0;
+    bool equal_bands = false;
+    std::vector<Rank> ranks;
+    ~GdptMulti() {
+        for (Rank &r : ranks) {
+            hipSetDevice(r.device);
+            if (r.comm) ncclCommDestroy(r.comm);
+            for (double *&b : r.buf) if (b) hipFree(b);
+            for (hipEvent_t &e : r.ev_t) if (e) hipEventDestroy(e);
+            if (r.ev_rendered) hipEventDestroy(r.ev_rendered);
+            if (r.ev_pushed) hipEventDestroy(r.ev_pushed);
+            if (r.stream) hipStreamDestroy(r.stream);
+            r.scene.reset();
+        }
+    }
+};
+
+namespace {
+
+// Everything one device does for one call; runs on that device's host thread.
+void rank_body(GdptMulti *m, int i, const GdptRenderParams *params, double alpha, HostBarrier *bar, bool want_stats) {
+    Rank &me = m->ranks[(size_t)i];
+    const int W = m->w, H = m->h, n = m->n;
+    const size_t row = (size_t)W * 3;
+    auto fail_safe = [&](auto &&fn) {            // a failing rank must still meet the others at every barrier
+        if (!me.error.empty()) return;
+        try { fn(); } catch (const std::exception &e) { me.error = e.what(); }
+    };
+    const bool owns = me.row_end > me.row_begin;
+    fail_safe([&] {
+        ck(hipSetDevice(me.device), "hipSetDevice");
+        ck(hipEventRecord(me.ev_t[0], me.stream), "hipEventRecord");
+        if (owns) {
+            GdptRenderParams p = params ? *params : GdptRenderParams{};
+            p.row_begin = me.row_begin; p.row_end = me.row_end;
+            if (me.row_begin == 0 && me.row_end == 0) throw std::runtime_error("empty band");   // (0,0) would mean "whole image"
+            gdpt::render_device_impl(me.scene.get(), &p, m->scene_spp, me.buf[0], me.buf[1], me.buf[2], me.buf[3], me.buf[4], me.stream, nullptr);
+        }
+        ck(hipEventRecord(me.ev_rendered, me.stream), "hipEventRecord");
+        ck(hipEventRecord(me.ev_t[1], me.stream), "hipEventRecord");
+    });
+    // neighbours in band order that own rows (ranks without rows are skipped, as sharding.halo_exchange_cy1 does)
+    int prev = -1, next = -1;
+    for (int j = i - 1; j >= 0; j--) if (m->ranks[(size_t)j].row_end > m->ranks[(size_t)j].row_begin) { prev = j; break; }
+    for (int j = i + 1; j < n; j++) if (m->ranks[(size_t)j].row_end > m->ranks[(size_t)j].row_begin) { next = j; break; }
+    bar->arrive_and_wait();                       // every ev_rendered is recorded
+    // a device that failed so far must not leave the others waiting inside a collective: everyone skips the exchange
+    bool any_failed = false;
+    for (const Rank &r : m->ranks) any_failed = any_failed || !r.error.empty();
+    if (any_failed) {
+        if (me.error.empty()) me.error = "skipped: another device of the set failed";
+        bar->arrive_and_wait();
+        hipStreamSynchronize(me.stream);
+        return;
+    }
+    // ---- halo: the last cy1 row of my band goes to the next band's device (row r1-1 of ITS cy1 image)
+    fail_safe([&] {
+        if (!owns) return;
+        if (m->exchange == GDPT_EXCHANGE_RCCL) {
+            if (n > 1) {
+                nk(ncclGroupStart(), "ncclGroupStart");
+                if (next >= 0) nk(ncclSend(me.buf[4] + (size_t)(me.row_end - 1) * row, row, ncclDouble, next, me.comm, me.stream), "ncclSend(halo)");
+                if (prev >= 0) nk(ncclRecv(me.buf[4] + (size_t)(me.row_begin - 1) * row, row, ncclDouble, prev, me.comm, me.stream), "ncclRecv(halo)");
+                nk(ncclGroupEnd(), "ncclGroupEnd");
+            }
+        } else if (prev >= 0) {                   // pull model: wait for the band above to be rendered, copy its last row
+            Rank &up = m->ranks[(size_t)prev];
+            ck(hipStreamWaitEvent(me.stream, up.ev_rendered, 0), "hipStreamWaitEvent");
+            ck(hipMemcpyPeerAsync(me.buf[4] + (size_t)(me.row_begin - 1) * row, me.device,
+                                  up.buf[4] + (size_t)(up.row_end - 1) * row, up.device, row * sizeof(double), me.stream), "hipMemcpyPeerAsync(halo)");
+        }
+        // ---- assemble own band (src/render.cpp:340-350)
+        gdpt::launch_assemble(W, H, me.row_begin, me.row_end, me.buf[0], me.buf[1], me.buf[2], me.buf[3], me.buf[4], me.buf[5], me.buf[6], me.buf[7], me.stream);
+    });
+    // ---- all-gather of c, cx, cy
+    fail_safe([&] {
+        if (n == 1) return;
+        if (m->exchange == GDPT_EXCHANGE_RCCL) {
+            nk(ncclGroupStart(), "ncclGroupStart");
+            if (m->equal_bands) {
+                const size_t band_elems = (size_t)(me.row_end - me.row_begin) * row;
+                for (int k = 5; k < 8; k++)       // in place: my band already sits at offset rank * band_elems
+                    nk(ncclAllGather(me.buf[k] + (size_t)me.row_begin * row, me.buf[k], band_elems, ncclDouble, me.comm, me.stream), "ncclAllGather");
+            } else {
+                for (int j = 0; j < n; j++) {
+                    const Rank &src = m->ranks[(size_t)j];
+                    if (src.row_end <= src.row_begin) continue;
+                    const size_t off = (size_t)src.row_begin * row, cnt = (size_t)(src.row_end - src.row_begin) * row;
+                    for (int k = 5; k < 8; k++) nk(ncclBroadcast(me.buf[k] + off, me.buf[k] + off, cnt, ncclDouble, j, me.comm, me.stream), "ncclBroadcast");
+                }
+            }
+            nk(ncclGroupEnd(), "ncclGroupEnd");
+        } else if (owns) {
+            // push my band into every other device's images. Nobody else writes those rows there (assembly is
+            // band-local), and their previous readers (the last call's solve) were waited for before it returned.
+            for (int j = 0; j < n; j++) {
+                if (j == i) continue;
+                Rank &dst = m->ranks[(size_t)j];
+                const size_t off = (size_t)me.row_begin * row, bytes = (size_t)(me.row_end - me.row_begin) * row * sizeof(double);
+                for (int k = 5; k < 8; k++)
+                    if (dst.buf[k] != me.buf[k])   // (the same device twice shares nothing: each rank has its own buffers)
+                        ck(hipMemcpyPeerAsync(dst.buf[k] + off, dst.device, me.buf[k] + off, me.device, bytes, me.stream), "hipMemcpyPeerAsync(band)");
+            }
+        }
+    });
+    fail_safe([&] { ck(hipEventRecord(me.ev_pushed, me.stream), "hipEventRecord"); });
+    bar->arrive_and_wait();                       // every ev_pushed is recorded
+    fail_safe([&] {
+        if (m->exchange == GDPT_EXCHANGE_PEER_COPY && i == 0)
+            for (int j = 1; j < n; j++) ck(hipStreamWaitEvent(me.stream, m->ranks[(size_t)j].ev_pushed, 0), "hipStreamWaitEvent");
+        ck(hipEventRecord(me.ev_t[2], me.stream), "hipEventRecord");
+        if (i == 0) {
+            gdpt::poisson_solve_device(W, H, me.buf[5], me.buf[6], me.buf[7], alpha, me.buf[8], GDPT_SOLVER_DCT, 0.0, 0, me.stream, false);
+        }
+        ck(hipEventRecord(me.ev_t[3], me.stream), "hipEventRecord");
+        ck(hipStreamSynchronize(me.stream), "hipStreamSynchronize");
+        if (want_stats && owns) {                 // counters of my band's render (the kernel has finished)
+            GdptScene *sc = me.scene.get();
+            ck(hipMemcpy(sc->h_counters, sc->d_counters, sizeof(gdpt::RenderCounters), hipMemcpyDeviceToHost), "hipMemcpy(counters)");
+            me.rstats = GdptRenderStats{};
+            me.rstats.rays = sc->h_counters->rays; me.rstats.bounces = sc->h_counters->bounces;
+            me.rstats.nonfinite_samples = sc->h_counters->nonfinite;
+            float ms = 0;
+            ck(hipEventElapsedTime(&ms, me.ev_t[0], me.ev_t[1]), "hipEventElapsedTime");
+            me.rstats.render_ms = ms;
+        }
+    });
+}
+
+} // namespace
+
+extern "C" {
+
+int gdpt_band_rows(int height, int num_bands, int band, int32_t *row_begin, int32_t *row_end) {
+    return gdpt::guarded([&]() {
+        if (height <= 0 || num_bands <= 0 || band < 0 || band >= num_bands || !row_begin || !row_end) throw std::runtime_error("gdpt_band_rows: bad argument");
+        int r0, r1;
+        band_rows(height, num_bands, band, &r0, &r1);
+        *row_begin = r0; *row_end = r1;
+    });
+}
+
+int gdpt_multi_create(const GdptSceneDesc *desc, const GdptMultiConfig *cfg, GdptMulti **out) {
+    return gdpt::guarded([&]() {
+        if (!desc || !cfg || !out) throw std::runtime_error("gdpt_multi_create: null argument");
+        if (cfg->num_devices <= 0 || cfg->num_devices > GDPT_MULTI_MAX_DEVICES) throw std::runtime_error("gdpt_multi_create: num_devices out of range");
+        if (cfg->exchange != GDPT_EXCHANGE_RCCL && cfg->exchange != GDPT_EXCHANGE_PEER_COPY) throw std::runtime_error("gdpt_multi_create: unknown exchange");
+        int ndev = 0;
+        ck(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+        if (ndev <= 0) throw std::runtime_error("gdpt_multi_create: no HIP device visible (this library has no CPU fallback)");
+        const int n = cfg->num_devices;
+        for (int i = 0; i < n; i++) {
+            if (cfg->devices[i] < 0 || cfg->devices[i] >= ndev)
+                throw std::runtime_error("gdpt_multi_create: device " + std::to_string(cfg->devices[i]) + " asked for, " + std::to_string(ndev) + " visible");
+            if (cfg->exchange == GDPT_EXCHANGE_RCCL)
+                for (int j = 0; j < i; j++) if (cfg->devices[j] == cfg->devices[i]) throw std::runtime_error("gdpt_multi_create: RCCL needs distinct devices (GDPT_EXCHANGE_PEER_COPY accepts a device twice)");
+        }
+        std::unique_ptr<GdptMulti> m(new GdptMulti());
+        m->n = n; m->w = desc->camera.width; m->h = desc->camera.height; m->exchange = cfg->exchange;
+        m->scene_spp = desc->samples_per_pixel;
+        if (m->w <= 0 || m->h <= 0) throw std::runtime_error("gdpt_multi_create: empty film");
+        m->ranks.resize((size_t)n);
+        const size_t elems = (size_t)m->w * m->h * 3;
+        bool equal = true;
+        for (int i = 0; i < n; i++) {
+            Rank &r = m->ranks[(size_t)i];
+            r.device = cfg->devices[i];
+            band_rows(m->h, n, i, &r.row_begin, &r.row_end);
+            if (r.row_end - r.row_begin != m->ranks[0].row_end - m->ranks[0].row_begin || r.row_end <= r.row_begin) equal = false;
+            r.scene.reset(new GdptScene());
+            gdpt::build_scene(desc, r.device, r.scene.get());       // sets the device
+            r.scene->scene_spp = desc->samples_per_pixel;
+            ck(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking), "hipStreamCreate");
+            for (double *&b : r.buf) { ck(hipMalloc((void **)&b, elems * sizeof(double)), "hipMalloc(band images)"); ck(hipMemset(b, 0, elems * sizeof(double)), "hipMemset"); }
+            for (hipEvent_t &e : r.ev_t) ck(hipEventCreate(&e), "hipEventCreate");
+            ck(hipEventCreateWithFlags(&r.ev_rendered, hipEventDisableTiming), "hipEventCreate");
+            ck(hipEventCreateWithFlags(&r.ev_pushed, hipEventDisableTiming), "hipEventCreate");
+        }
+        m->equal_bands = equal;
+        if (cfg->exchange == GDPT_EXCHANGE_PEER_COPY) {
+            for (int i = 0; i < n; i++)
+                for (int j = 0; j < n; j++) {
+                    const int a = m->ranks[(size_t)i].device, b = m->ranks[(size_t)j].device;
+                    if (a == b) continue;
+                    int can = 0;
+                    ck(hipDeviceCanAccessPeer(&can, a, b), "hipDeviceCanAccessPeer");
+                    if (!can) throw std::runtime_error("gdpt_multi_create: devices " + std::to_string(a) + " and " + std::to_string(b) + " have no peer access");
+                    ck(hipSetDevice(a), "hipSetDevice");
+                    hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ck(e, "hipDeviceEnablePeerAccess");
+                    (void)hipGetLastError();
+                }
+        } else if (n > 1) {
+            std::vector<ncclComm_t> comms((size_t)n);
+            nk(ncclCommInitAll(comms.data(), n, cfg->devices), "ncclCommInitAll");
+            for (int i = 0; i < n; i++) m->ranks[(size_t)i].comm = comms[(size_t)i];
+        }
+        *out = m.release();
+    });
+}
+
+void gdpt_multi_free(GdptMulti *m) { delete m; }
+
+int gdpt_multi_gradient_path_render(GdptMulti *m, const GdptRenderParams *params, double dataCost, double *out_image,
+                                    double *img, double *cx0, double *cy0, double *cx1, double *cy1,
+                                    GdptRenderStats *rstats, GdptMultiStats *mstats) {
+    return gdpt::guarded([&]() {
+        if (!m || !out_image) throw std::runtime_error("gdpt_multi_gradient_path_render: null argument");
+        if (params && (params->row_begin != 0 || params->row_end != 0)) throw std::runtime_error("gdpt_multi_gradient_path_render: the bands are chosen by the library (row_begin/row_end must be 0)");
+        const auto t0 = std::chrono::steady_clock::now();
+        HostBarrier bar(m->n);
+        const bool want = rstats != nullptr || mstats != nullptr;
+        for (Rank &r : m->ranks) r.error.clear();
+        std::vector<std::thread> threads;
+        for (int i = 1; i < m->n; i++) threads.emplace_back(rank_body, m, i, params, dataCost, &bar, want);
+        rank_body(m, 0, params, dataCost, &bar, want);        // the calling thread drives device 0, as parallel_for's caller
+        for (auto &t : threads) t.join();                     // takes part in the tile loop (src/parallel.cpp:204-236)
+        for (int pass = 0; pass < 2; pass++)                  // report the device that failed, not the ones that stood down for it
+            for (int i = 0; i < m->n; i++) {
+                const std::string &e = m->ranks[(size_t)i].error;
+                if (!e.empty() && (pass == 1 || e.compare(0, 8, "skipped:") != 0))
+                    throw std::runtime_error("device " + std::to_string(m->ranks[(size_t)i].device) + " (band " + std::to_string(i) + "): " + e);
+            }
+        Rank &r0 = m->ranks[0];
+        const size_t elems = (size_t)m->w * m->h * 3, row = (size_t)m->w * 3;
+        ck(hipSetDevice(r0.device), "hipSetDevice");
+        ck(hipMemcpy(out_image, r0.buf[8], elems * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
+        double *host[5] = {img, cx0, cy0, cx1, cy1};
+        for (int k = 0; k < 5; k++) {
+            if (!host[k]) continue;
+            for (Rank &r : m->ranks) {                        // the raw accumulation buffers stay sharded: collect band by band
+                if (r.row_end <= r.row_begin) continue;
+                ck(hipSetDevice(r.device), "hipSetDevice");
+                ck(hipMemcpy(host[k] + (size_t)r.row_begin * row, r.buf[k] + (size_t)r.row_begin * row,
+                             (size_t)(r.row_end - r.row_begin) * row * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(D2H band)");
+            }
+        }
+        if (rstats) {
+            *rstats = GdptRenderStats{};
+            int spp = (params && params->spp > 0) ? params->spp : m->scene_spp;
+            rstats->samples = (uint64_t)m->w * (uint64_t)m->h * (uint64_t)spp;
+            for (Rank &r : m->ranks) {
+                rstats->rays += r.rstats.rays; rstats->bounces += r.rstats.bounces; rstats->nonfinite_samples += r.rstats.nonfinite_samples;
+                rstats->render_ms = std::max(rstats->render_ms, r.rstats.render_ms);
+            }
+        }
+        if (mstats) {
+            *mstats = GdptMultiStats{};
+            mstats->num_devices = m->n; mstats->exchange = m->exchange;
+            for (int i = 0; i < m->n; i++) {
+                Rank &r = m->ranks[(size_t)i];
+                float a = 0, b = 0, c = 0;
+                ck(hipSetDevice(r.device), "hipSetDevice");
+                ck(hipEventElapsedTime(&a, r.ev_t[0], r.ev_t[1]), "hipEventElapsedTime");
+                ck(hipEventElapsedTime(&b, r.ev_t[1], r.ev_t[2]), "hipEventElapsedTime");
+                ck(hipEventElapsedTime(&c, r.ev_t[2], r.ev_t[3]), "hipEventElapsedTime");
+                mstats->render_ms[i] = a; mstats->row_begin[i] = r.row_begin; mstats->row_end[i] = r.row_end;
+                mstats->render_ms_max = std::max(mstats->render_ms_max, (double)a);
+                mstats->exchange_ms = std::max(mstats->exchange_ms, (double)b);     // includes waiting for the slowest band
+                if (i == 0) mstats->solve_ms = c;
+            }
+            mstats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+    });
+}
+
+} // extern "C"

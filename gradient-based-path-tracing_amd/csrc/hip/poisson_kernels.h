@@ -6,8 +6,8 @@ namespace gdpt {
 
 struct PoissonResult { int iterations; int solver; double rel_residual; double solve_ms; };
 
-// c=img; cx=cx0(x,y)+cx1(x-1,y); cy=cy0(x,y)+cy1(x,y-1)   (src/render.cpp:340-350)
-void launch_assemble(int w, int h, const double *img, const double *cx0, const double *cy0, const double *cx1, const double *cy1,
+// c=img; cx=cx0(x,y)+cx1(x-1,y); cy=cy0(x,y)+cy1(x,y-1)   (src/render.cpp:340-350), rows [row_begin,row_end) (0,0 = all)
+void launch_assemble(int w, int h, int row_begin, int row_end, const double *img, const double *cx0, const double *cy0, const double *cx1, const double *cy1,
                      double *c, double *cx, double *cy, hipStream_t stream);
 
 // Screened Poisson solve on device buffers (W*H*3 doubles, interleaved RGB), reproducing fourierSolve

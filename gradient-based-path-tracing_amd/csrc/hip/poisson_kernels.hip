@@ -83,9 +83,12 @@ __device__ __forceinline__ double laplace(const Geo &g, int i, int x, int y, dou
     return lx + ly;
 }
 
-__global__ __launch_bounds__(kBlock) void assemble_kernel(Geo g, const double *img, const double *cx0, const double *cy0,
+// rows [row_begin, row_end) only: a rank of the sharded tile loop assembles its own band (cy of the band's first row
+// reads the halo row row_begin-1 of cy1, which the rank above has sent)
+__global__ __launch_bounds__(kBlock) void assemble_kernel(Geo g, int row_begin, int row_end, const double *img, const double *cx0, const double *cy0,
                                                           const double *cx1, const double *cy1, double *c, double *cx, double *cy) {
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < g.n3; i += gridDim.x * kBlock) {
+    const int lo = row_begin * g.row, hi = row_end * g.row;
+    for (int i = lo + blockIdx.x * kBlock + threadIdx.x; i < hi; i += gridDim.x * kBlock) {
         int y = i / g.row, x = (i - y * g.row) / 3;
         c[i] = img[i];
         cx[i] = (x == 0) ? cx0[i] : cx0[i] + cx1[i - 3];
@@ -461,12 +464,15 @@ void poisson_release_workspace() {
     hipSetDevice(cur);
 }
 
-void launch_assemble(int w, int h, const double *img, const double *cx0, const double *cy0, const double *cx1, const double *cy1,
-                     double *c, double *cx, double *cy, hipStream_t stream) {
+void launch_assemble(int w, int h, int row_begin, int row_end, const double *img, const double *cx0, const double *cy0, const double *cx1,
+                     const double *cy1, double *c, double *cx, double *cy, hipStream_t stream) {
     if (w <= 0 || h <= 0) throw std::runtime_error("assemble: empty image");
+    if (row_begin == 0 && row_end == 0) row_end = h;
+    if (row_begin < 0 || row_end > h || row_begin >= row_end) throw std::runtime_error("assemble: bad row band");
     gp::Geo g{w, h, w * h * 3, w * 3};
-    int nb = std::min(gp::kMaxBlocks * 2, (g.n3 + gp::kBlock - 1) / gp::kBlock);
-    hipLaunchKernelGGL(gp::assemble_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, img, cx0, cy0, cx1, cy1, c, cx, cy);
+    const int n = (row_end - row_begin) * g.row;
+    int nb = std::min(gp::kMaxBlocks * 2, (n + gp::kBlock - 1) / gp::kBlock);
+    hipLaunchKernelGGL(gp::assemble_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, row_begin, row_end, img, cx0, cy0, cx1, cy1, c, cx, cy);
     ck(hipGetLastError(), "assemble kernel launch");
 }
 

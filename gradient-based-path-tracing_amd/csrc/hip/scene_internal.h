@@ -1,0 +1,72 @@
+// scene_internal.h — the device-resident scene handle and the render entry shared by the C-ABI translation units
+// (capi_device.hip: single-device entry points; multi_gpu.hip: the row-band host of several devices).
+#pragma once
+#include "../../../include/gdpt.h"
+#include "../device_scene.h"
+#include "render_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace gdpt {
+inline void ck(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+} // namespace gdpt
+
+struct GdptScene {
+    int device = 0;
+    DevSceneView view{};
+    int bvh_depth = 0;
+    int wide_stack_need = 0;
+    bool has_envmap = false;
+    int scene_spp = 0;             // <sampler sampleCount> of the description (default spp)
+    bool one_sided = true, lambert_only = true;
+    bool has_rough = false;        // RoughPlastic / RoughDielectric present: GradPath uses the evaluator built with those lobes
+    std::vector<void *> allocations;
+    // cached output/work buffers for the host-pointer entry points
+    double *d_buf[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t buf_elems = 0;
+    gdpt::RenderCounters *d_counters = nullptr;
+    gdpt::RenderCounters *h_counters = nullptr; // pinned
+    void *d_bounce_log = nullptr; size_t bounce_log_bytes = 0;   // per-lane bounce log of the two-sided lane machine
+    double *d_partials = nullptr; size_t partials_doubles = 0;   // work-item partial sums of the persistent render kernel
+    unsigned long long *d_queue = nullptr;
+    int num_cus = 256;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    template <class T>
+    T *keep(T *p) { if (p) allocations.push_back((void *)p); return p; }
+
+    void ensure_buffers(size_t elems) {
+        if (elems <= buf_elems) return;
+        for (auto &b : d_buf) { if (b) hipFree(b); b = nullptr; }
+        for (auto &b : d_buf) gdpt::ck(hipMalloc((void **)&b, elems * sizeof(double)), "hipMalloc(image buffers)");
+        buf_elems = elems;
+    }
+    ~GdptScene() {
+        hipSetDevice(device);
+        for (void *p : allocations) hipFree(p);
+        for (auto &b : d_buf) if (b) hipFree(b);
+        if (d_counters) hipFree(d_counters);
+        if (d_partials) hipFree(d_partials);
+        if (d_bounce_log) hipFree(d_bounce_log);
+        if (d_queue) hipFree(d_queue);
+        if (h_counters) hipHostFree(h_counters);
+        if (ev0) hipEventDestroy(ev0);
+        if (ev1) hipEventDestroy(ev1);
+    }
+};
+
+
+namespace gdpt {
+// Own BVH build + HBM upload of a flattened scene (replaces Scene::Scene, src/scene.cpp:4-53).
+void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc);
+// Enqueues one five-buffer render of rows [params->row_begin, row_end) on `stream`; waits only when `stats` is given.
+void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene_spp,
+                        double *img, double *cx0, double *cy0, double *cx1, double *cy1,
+                        hipStream_t stream, GdptRenderStats *stats);
+} // namespace gdpt

@@ -259,6 +259,7 @@ ParsedTexture parse_texture(const XmlNode &node, const DefaultMap &dm) {
 struct Builder {
     HostScene &hs;
     DefaultMap dm;
+    int film_w = 0, film_h = 0;       // > 0: replaces the <film> extent (benchmark configurations quote their own)
     std::map<std::string, int> material_map;
     std::map<std::string, ParsedTexture> texture_map;
     std::map<std::string, int> image3_map, image1_map; // TexturePool::image3s_map / image1s_map (src/texture.h:10-16)
@@ -621,6 +622,8 @@ struct Builder {
                 }
             }
         }
+        if (film_w > 0) width = film_w;
+        if (film_h > 0) height = film_h;
         // to fovX (parse_scene.cpp:842-855)
         if (axis == AY || (axis == ASMALL && height < width) || (axis == ALARGE && width < height)) {
             double aspect = width / (double)height;
@@ -985,7 +988,7 @@ HostMesh load_serialized(const std::string &filename, int shape_index, const M4 
     return mesh;
 }
 
-std::unique_ptr<HostScene> load_scene_xml(const std::string &path) {
+std::unique_ptr<HostScene> load_scene_xml(const std::string &path, int film_width, int film_height) {
     std::ifstream f(path, std::ios::binary);
     if (!f.is_open()) fail("Parse error: cannot open " + path);
     std::string text((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
@@ -997,6 +1000,7 @@ std::unique_ptr<HostScene> load_scene_xml(const std::string &path) {
     // the reference chdir()s into the scene's folder while parsing (parse_scene.cpp:1624-1628);
     // resolve relative asset paths against it instead of changing the process cwd
     b.scene_dir = fs::path(path).parent_path();
+    b.film_w = film_width; b.film_h = film_height;
     if (scene) b.run(*scene);
     else b.run(XmlNode{}); // pugixml yields an empty node: defaults everywhere
     hs->finalize();

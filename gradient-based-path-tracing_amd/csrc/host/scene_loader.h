@@ -30,7 +30,8 @@ struct HostScene {
 };
 
 // Throws std::runtime_error with the reference's wording where it has one (src/flexception.h).
-std::unique_ptr<HostScene> load_scene_xml(const std::string &path);
+// film_width / film_height > 0 replace the extent of the scene's <film> (the camera is built for the new aspect).
+std::unique_ptr<HostScene> load_scene_xml(const std::string &path, int film_width = 0, int film_height = 0);
 
 // Pieces exposed for unit tests / golden checks against the reference's own functions.
 HostMesh load_obj(const std::string &filename, const M4 &to_world);          // src/parsers/parse_obj.cpp:94-185

@@ -9,6 +9,10 @@
 //   --rng tile|sample   PCG stream assignment (default sample; tile = the reference's order, slow)
 //   --alpha A     Poisson data weight (default 0.04, src/render.cpp:353)
 //   --device D    GPU index
+//   --film WxH    replace the scene's <film> extent (benchmark configurations quote their own)
+//   --gpus N      shard the tile loop into N row bands over devices 0..N-1 (gdpt_multi_*: one host thread per GPU, as
+//                 the reference's -t threads share the tile grid, src/parallel.cpp:183-256); --devices a,b,.. names them
+//   --exchange rccl|peer   transport of the halo row + all-gather between the bands (default rccl)
 // `-t` is accepted for compatibility; rendering runs on the GPU, so it has no effect.
 #include "../../include/gdpt.h"
 
@@ -25,6 +29,8 @@ int main(int argc, char *argv[]) {
         return 0;
     }
     int num_threads = 0, spp = 0, device = 0, rng = GDPT_RNG_SAMPLE, shift = GDPT_SHIFT_REFERENCE;
+    int film_w = 0, film_h = 0;
+    GdptMultiConfig multi{};          // num_devices == 0: single-device entry points
     double alpha = 0.04;
     std::string outputfile = "";
     std::vector<std::string> filenames;
@@ -37,6 +43,35 @@ int main(int argc, char *argv[]) {
         else if (a == "--ref-spp") spp = 1000;
         else if (a == "--alpha") alpha = std::stod(next());
         else if (a == "--device") device = std::stoi(next());
+        else if (a == "--film") {
+            std::string v = next();
+            size_t xpos = v.find('x');
+            if (xpos == std::string::npos) { std::cerr << "--film expects WxH" << std::endl; return 2; }
+            film_w = std::stoi(v.substr(0, xpos)); film_h = std::stoi(v.substr(xpos + 1));
+        }
+        else if (a == "--gpus") {
+            multi.num_devices = std::stoi(next());
+            if (multi.num_devices < 1 || multi.num_devices > GDPT_MULTI_MAX_DEVICES) { std::cerr << "--gpus out of range" << std::endl; return 2; }
+            for (int k = 0; k < multi.num_devices; k++) multi.devices[k] = k;
+        }
+        else if (a == "--devices") {      // comma-separated HIP ordinals, band order
+            std::string v = next();
+            multi.num_devices = 0;
+            size_t pos = 0;
+            while (pos <= v.size()) {
+                size_t c = v.find(',', pos);
+                if (c == std::string::npos) c = v.size();
+                if (multi.num_devices >= GDPT_MULTI_MAX_DEVICES) { std::cerr << "--devices: too many" << std::endl; return 2; }
+                multi.devices[multi.num_devices++] = std::stoi(v.substr(pos, c - pos));
+                pos = c + 1;
+            }
+        }
+        else if (a == "--exchange") {
+            std::string v = next();
+            if (v == "rccl") multi.exchange = GDPT_EXCHANGE_RCCL;
+            else if (v == "peer") multi.exchange = GDPT_EXCHANGE_PEER_COPY;
+            else { std::cerr << "unknown --exchange " << v << " (rccl | peer)" << std::endl; return 2; }
+        }
         else if (a == "--rng") { std::string v = next(); rng = (v == "tile") ? GDPT_RNG_TILE : GDPT_RNG_SAMPLE; }
         else if (a == "--shift") {        // extension: "reconnect" = GDPT_SHIFT_RECONNECT (include/gdpt.h); default = the reference's offsets
             std::string v = next();
@@ -53,7 +88,7 @@ int main(int argc, char *argv[]) {
         auto t0 = clock::now();
         std::cout << "Parsing and constructing scene " << filename << "." << std::endl;
         GdptSceneDesc *desc = nullptr;
-        if (gdpt_parse_scene(filename.c_str(), &desc) != 0) {
+        if (gdpt_parse_scene_film(filename.c_str(), film_w, film_h, &desc) != 0) {
             std::cerr << "terminate: " << gdpt_last_error() << std::endl;   // the reference dies on an uncaught fl_exception
             return 134;
         }
@@ -61,8 +96,10 @@ int main(int argc, char *argv[]) {
             std::cerr << "terminate: this build implements Integrator::GradPath and Integrator::Path (scene asks for another integrator)" << std::endl;
             return 134;
         }
+        const bool sharded = multi.num_devices > 0 && desc->integrator == GDPT_INTEGRATOR_GRADPATH;
         GdptScene *scene = nullptr;
-        if (gdpt_scene_upload(desc, device, &scene) != 0) {
+        GdptMulti *mscene = nullptr;
+        if ((sharded ? gdpt_multi_create(desc, &multi, &mscene) : gdpt_scene_upload(desc, device, &scene)) != 0) {
             std::cerr << "terminate: " << gdpt_last_error() << std::endl;
             return 134;
         }
@@ -75,10 +112,14 @@ int main(int argc, char *argv[]) {
         p.spp = spp; p.rng_scheme = rng; p.shift_mode = shift;
         GdptRenderStats rs{};
         GdptPoissonStats ps{};
+        GdptMultiStats ms{};
         // render() dispatches on the integrator (src/render.cpp:374-392)
-        const int rc = (desc->integrator == GDPT_INTEGRATOR_PATH)
-                           ? gdpt_path_render(scene, &p, image.data(), &rs)
-                           : gdpt_gradient_path_render(scene, &p, alpha, image.data(), nullptr, nullptr, nullptr, nullptr, nullptr, &rs, &ps);
+        int rc;
+        if (sharded) {
+            rc = gdpt_multi_gradient_path_render(mscene, &p, alpha, image.data(), nullptr, nullptr, nullptr, nullptr, nullptr, &rs, &ms);
+            ps.solve_ms = ms.solve_ms; ps.solver = GDPT_SOLVER_DCT;
+        } else if (desc->integrator == GDPT_INTEGRATOR_PATH) rc = gdpt_path_render(scene, &p, image.data(), &rs);
+        else rc = gdpt_gradient_path_render(scene, &p, alpha, image.data(), nullptr, nullptr, nullptr, nullptr, nullptr, &rs, &ps);
         if (rc != 0) {
             std::cerr << "terminate: " << gdpt_last_error() << std::endl;
             return 134;
@@ -97,6 +138,12 @@ int main(int argc, char *argv[]) {
         std::cout << "[gdpt] " << rs.samples << " samples, " << rs.rays << " rays, render " << rs.render_ms << " ms ("
                   << (rs.render_ms > 0 ? rs.samples / rs.render_ms / 1e3 : 0.0) << " Msamples/s), Poisson " << ps.iterations
                   << " CG iterations " << ps.solve_ms << " ms, non-finite samples " << rs.nonfinite_samples << std::endl;
+        if (sharded) {
+            std::cout << "[gdpt] " << ms.num_devices << " row bands (" << (ms.exchange == GDPT_EXCHANGE_RCCL ? "RCCL" : "peer copies") << "): render";
+            for (int k = 0; k < ms.num_devices; k++) std::cout << " " << ms.render_ms[k];
+            std::cout << " ms, halo+assemble+gather " << ms.exchange_ms << " ms, solve " << ms.solve_ms << " ms, wall " << ms.wall_ms << " ms" << std::endl;
+        }
+        gdpt_multi_free(mscene);
         gdpt_scene_free(scene);
         gdpt_free_scene_desc(desc);
     }

@@ -16,6 +16,16 @@ Backend-agnostic: works with torch.distributed over RCCL ("nccl") on GPUs and ov
 TILE = 16  # src/render.cpp:271
 
 
+def wire_device(dist, t):
+    """Device the exchanged bytes travel from: the tensor's own under RCCL; host memory under gloo, which has no
+    device-side all-gather / send-recv (rehearsals of the N>1 step on one GPU, `bench.py --dist-backend gloo`; the copies
+    to and from the wire buffers are plain tensor copies, so the exchange code below is the same in both cases)."""
+    if t.is_cuda and dist is not None and dist.get_backend() == "gloo":
+        import torch
+        return torch.device("cpu")
+    return t.device
+
+
 def band_rows(height, world, rank):
     """Rows [r0, r1) owned by `rank`: whole tile rows, balanced by tile-row count, in rank order."""
     if world <= 0 or not (0 <= rank < world):
@@ -39,6 +49,12 @@ def gather_bands(dist, buf, height, world, rank):
     bands = all_bands(height, world)
     r0, r1 = bands[rank]
     sizes = {b[1] - b[0] for b in bands}
+    wire = wire_device(dist, buf)
+    if wire != buf.device:            # gloo over device tensors: gather a host copy, write it back
+        host = buf.to(wire)
+        gather_bands(dist, host, height, world, rank)
+        buf.copy_(host)
+        return buf
     mine = buf[r0:r1].reshape(-1)
     if len(sizes) == 1 and bands[-1][1] == height:
         dist.all_gather_into_tensor(buf.view(-1), mine.clone())
@@ -74,10 +90,11 @@ def halo_exchange_cy1(dist, cy1, height, world, rank):
     owners = [r for r in range(world) if bands[r][1] > bands[r][0]]
     if r1 > r0:
         i = owners.index(rank)
+        wire = wire_device(dist, cy1)
         if i + 1 < len(owners):
-            ops.append(dist.P2POp(dist.isend, cy1[r1 - 1].contiguous(), owners[i + 1]))
+            ops.append(dist.P2POp(dist.isend, cy1[r1 - 1].contiguous().to(wire), owners[i + 1]))
         if i > 0:
-            recv_row = cy1.new_empty(cy1[r0 - 1].shape)
+            recv_row = cy1.new_empty(cy1[r0 - 1].shape, device=wire)
             ops.append(dist.P2POp(dist.irecv, recv_row, owners[i - 1]))
     if ops:
         for req in dist.batch_isend_irecv(ops):
@@ -101,11 +118,12 @@ def gather_packed(dist, images, height, world, rank, scratch=None):
     n = len(images)
     band_elems = (r1 - r0) * images[0].shape[1] * images[0].shape[2]
     scratch = {} if scratch is None else scratch
-    key = (n, band_elems, images[0].dtype, images[0].device)
+    wire = wire_device(dist, images[0])
+    key = (n, band_elems, images[0].dtype, wire)
     if scratch.get("key") != key:
         scratch["key"] = key
-        scratch["send"] = images[0].new_empty((n, band_elems))
-        scratch["recv"] = images[0].new_empty((world, n, band_elems))
+        scratch["send"] = images[0].new_empty((n, band_elems), device=wire)
+        scratch["recv"] = images[0].new_empty((world, n, band_elems), device=wire)
     send, recv = scratch["send"], scratch["recv"]
     for i, im in enumerate(images):
         send[i].copy_(im[r0:r1].reshape(-1))
@@ -113,3 +131,49 @@ def gather_packed(dist, images, height, world, rank, scratch=None):
     for i, im in enumerate(images):      # [world][band] of image i is the image itself (bands are rank-ordered)
         im.view(world, band_elems).copy_(recv[:, i])
     return images
+
+
+class ShardedGradPath:
+    """One rank's view of the sharded hot path — the step bench.py times and the gloo tests drive:
+
+        render own band -> last cy1 row to the band below -> assemble own band -> ONE packed all-gather of c, cx, cy
+        -> global screened-Poisson solve (replicated on every rank)
+
+    The class owns the order of those phases and the exchange between ranks (halo_exchange_cy1, gather_packed); what a
+    phase computes is injected, so the same step runs over RCCL with the HIP kernels (bench.py: device pointers of torch
+    CUDA tensors) and over gloo with CPU tensors (tests):
+
+        render_band(bufs, rows, want_stats)   fills rows [r0, r1) of the five tensors img, cx0, cy0, cx1, cy1
+        assemble(bufs, (c, cx, cy), rows)     src/render.cpp:340-350 on rows [r0, r1)
+        solve(c, cx, cy, out, want_stats)     fourierSolve, src/render.cpp:172-254
+        new_image()                           a zeroed HxWx3 float64 tensor on the rank's device
+        phase_hook(name)                      optional; called after 'render', 'exchange', 'solve' (per-phase timing)
+
+    `dist` is torch.distributed (any backend) or None when world == 1.
+    """
+
+    NAMES = ("img", "cx0", "cy0", "cx1", "cy1")
+
+    def __init__(self, dist, world, rank, height, new_image, render_band, assemble, solve, phase_hook=None):
+        self.dist, self.world, self.rank, self.height = dist, int(world), int(rank), int(height)
+        self.rows = band_rows(self.height, self.world, self.rank)
+        self.render_band, self.assemble, self.solve = render_band, assemble, solve
+        self.phase_hook = phase_hook or (lambda name: None)
+        self.bufs = {k: new_image() for k in self.NAMES}
+        self.c, self.cx, self.cy, self.out = (new_image() for _ in range(4))
+        self._scratch = {}
+
+    def step(self, want_stats=False):
+        r0, r1 = self.rows
+        rstats = self.render_band(self.bufs, self.rows, want_stats) if r1 > r0 else None
+        self.phase_hook("render")
+        if self.world > 1:            # exchange 1: the last cy1 row of the band above (W*24 bytes, point to point)
+            halo_exchange_cy1(self.dist, self.bufs["cy1"], self.height, self.world, self.rank)
+        if r1 > r0:
+            self.assemble(self.bufs, (self.c, self.cx, self.cy), self.rows)
+        if self.world > 1:            # exchange 2: ONE packed all-gather of the assembled bands
+            gather_packed(self.dist, [self.c, self.cx, self.cy], self.height, self.world, self.rank, self._scratch)
+        self.phase_hook("exchange")
+        pstats = self.solve(self.c, self.cx, self.cy, self.out, want_stats)
+        self.phase_hook("solve")
+        return rstats, pstats

@@ -12,6 +12,7 @@
  *   gdpt_poisson_solve      <- fourierSolve()           src/render.cpp:172-254 (argument-for-argument)
  *   gdpt_gradient_path_render <- gradient_path_render() src/render.cpp:257-370 (whole: render + assemble + solve)
  *   gdpt_imwrite            <- imwrite()                src/image.cpp:135-173
+ *   gdpt_multi_*            <- parallel_for tile pool   src/parallel.cpp:183-256, src/render.cpp:271-277 (bands over several GPUs)
  *
  * Plain pointers and sizes only; no C++/torch types. All images are row-major
  * `data[(y*W+x)*3+c]` fp64, exactly `Image3::data` (src/image.h:13-39).
@@ -189,6 +190,9 @@ typedef struct GdptScene GdptScene;   /* opaque: device-resident scene (BVH2 + B
 
 /* ---- host-side scene ingest (Mitsuba-0.x XML subset) ---- */
 int gdpt_parse_scene(const char *xml_path, GdptSceneDesc **out_desc);
+/* Same with the <film> extent replaced (0 = keep the scene's): the benchmark configurations quote their own film
+ * sizes (sponza at 1280x720, cbox at 1024x1024); the camera is built for the new aspect ratio, as if the XML said so. */
+int gdpt_parse_scene_film(const char *xml_path, int film_width, int film_height, GdptSceneDesc **out_desc);
 void gdpt_free_scene_desc(GdptSceneDesc *desc);
 
 /* ---- device scene ---- */
@@ -253,6 +257,52 @@ int gdpt_gradient_path_render(GdptScene *scene, const GdptRenderParams *params, 
                               double *out_image,
                               double *img, double *cx0, double *cy0, double *cx1, double *cy1,
                               GdptRenderStats *rstats, GdptPoissonStats *pstats);
+
+/* ---- several devices of one node: the tile loop sharded into row bands ----
+ * Replaces the reference's only parallelism, parallel_for over 16x16 tiles on a std::thread pool
+ * (src/render.cpp:271-277, src/parallel.cpp:183-256): contiguous bands of whole tile rows go to the devices, one host
+ * thread per device; between render and solve each device sends the last cy1 row of its band to the next one
+ * (src/render.cpp:345-349 needs it), assembles c, cx, cy for its own band, and the three images are all-gathered in
+ * place; the global solve runs on devices[0]. Results equal the single-device entry points bit for bit (same per-sample
+ * RNG streams, same per-pixel summation order). */
+#define GDPT_MULTI_MAX_DEVICES 16
+/* Transport of the halo row and the all-gather.
+ *   GDPT_EXCHANGE_RCCL:      ncclSend/ncclRecv + grouped in-place ncclAllGather (ncclBroadcast per band when the bands are
+ *                            ragged) on one communicator per device; devices must be distinct.
+ *   GDPT_EXCHANGE_PEER_COPY: direct device-to-device copies (hipMemcpyPeerAsync over xGMI, ordered by events): every device
+ *                            pushes its band to every other one, N-1 links at once. Accepts a device twice. */
+enum { GDPT_EXCHANGE_RCCL = 0, GDPT_EXCHANGE_PEER_COPY = 1 };
+typedef struct GdptMultiConfig {
+    int32_t num_devices;       /* 1..GDPT_MULTI_MAX_DEVICES */
+    int32_t exchange;          /* GDPT_EXCHANGE_* */
+    int32_t devices[GDPT_MULTI_MAX_DEVICES];   /* HIP device ordinals, band order */
+} GdptMultiConfig;
+typedef struct GdptMultiStats {
+    int32_t num_devices, exchange;
+    int32_t row_begin[GDPT_MULTI_MAX_DEVICES], row_end[GDPT_MULTI_MAX_DEVICES];
+    double render_ms[GDPT_MULTI_MAX_DEVICES];  /* device time of each band's render (HIP events) */
+    double render_ms_max;      /* slowest band */
+    double exchange_ms;        /* halo + assembly + all-gather, slowest device (includes waiting for the slowest band) */
+    double solve_ms;           /* Poisson solve on devices[0] */
+    double wall_ms;            /* host wall time of the call, D2H of the results included */
+} GdptMultiStats;
+typedef struct GdptMulti GdptMulti;   /* opaque: one uploaded scene, stream and image set per device (+ communicators) */
+
+/* Rows [row_begin,row_end) of band `band` of `num_bands`: whole 16-pixel tile rows (src/render.cpp:271), balanced by
+ * tile-row count, in band order. Host only. */
+int gdpt_band_rows(int height, int num_bands, int band, int32_t *row_begin, int32_t *row_end);
+int gdpt_multi_create(const GdptSceneDesc *desc, const GdptMultiConfig *config, GdptMulti **out);
+void gdpt_multi_free(GdptMulti *multi);
+/* Whole Integrator::GradPath on the device set; arguments as gdpt_gradient_path_render (params->row_begin/row_end
+ * must be 0: the library chooses the bands). Blocking. */
+int gdpt_multi_gradient_path_render(GdptMulti *multi, const GdptRenderParams *params, double dataCost, double *out_image,
+                                    double *img, double *cx0, double *cy0, double *cx1, double *cy1,
+                                    GdptRenderStats *rstats /* nullable */, GdptMultiStats *mstats /* nullable */);
+/* gdpt_assemble_device restricted to rows [row_begin,row_end) (0,0 = all): what one band owner runs. */
+int gdpt_assemble_rows_device(int width, int height, int row_begin, int row_end,
+                              const double *d_img, const double *d_cx0, const double *d_cy0,
+                              const double *d_cx1, const double *d_cy1,
+                              double *d_c, double *d_cx, double *d_cy, void *stream);
 
 /* ---- output ---- */
 /* By suffix: ".pfm" (fp32, header "PF\nW H\n-1\n", rows as stored) or ".exr" (fp16 RGB scanline). */

@@ -1,0 +1,49 @@
+"""`python bench.py --gpus N` as typed: the launcher starts N fresh rank processes, relays rank 0's line and fails
+loudly when a rank fails or the node has too few GPUs. The ranks here run bench.py's own sharded step
+(gdpt_amd.sharding.ShardedGradPath: band render -> cy1 halo -> band assembly -> packed all-gather -> solve) over gloo, the
+CPU oracle standing in for the GPU phases (tests/_rank_child.py); every rank must end with the single-process image."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, scene_variant
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+@pytest.mark.parametrize("world,height", [(2, 64), (3, 80)])
+def test_launcher_runs_the_sharded_step_on_every_rank(G, O, scene_tmp, tmp_path, world, height, capfd):
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=24, height=height)
+    sd = G.parse_scene(xml)
+    whole, _ = O.OracleScene(sd.ptr).render(2, G.RNG_SAMPLE, threads=4)
+    c, cx, cy = O.assemble(whole)
+    want = O.fourier_solve(c, cx, cy, 0.04)
+    rc = bench.launch_ranks(world, [os.path.join(ROOT, "tests", "_rank_child.py"), xml, "2", str(tmp_path)], timeout=300)
+    assert rc == 0
+    line = [l for l in capfd.readouterr().out.splitlines() if l.startswith("{")][-1]      # rank 0's line came through the parent
+    assert json.loads(line)["world"] == world
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        for name, w in (("c", c), ("cx", cx), ("cy", cy), ("out", want)):
+            assert np.array_equal(got[name], w), (r, name)
+
+
+def test_launcher_reports_a_failing_rank(tmp_path):
+    bad = tmp_path / "bad_rank.py"
+    bad.write_text("import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(7)\ntime.sleep(30)\n")
+    rc = bench.launch_ranks(2, [str(bad)], timeout=60)
+    assert rc == 7                                   # rank 0 (still sleeping) was ended, the failure is the exit status
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    import torch
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 2)], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert f"needs {n + 2} GPUs" in r.stderr and "visible" in r.stderr
+    assert not r.stdout.strip()                      # no JSON line pretending to be a measurement

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(G):
 def test_struct_layouts_match_the_header(G, tmp_path):
     src = tmp_path / "sz.c"
     structs = ["GdptTexture", "GdptMaterial", "GdptImage", "GdptShape", "GdptLight", "GdptCamera", "GdptSceneDesc",
-               "GdptRenderParams", "GdptRenderStats", "GdptPoissonStats"]
+               "GdptRenderParams", "GdptRenderStats", "GdptPoissonStats", "GdptMultiConfig", "GdptMultiStats"]
     body = "\n".join(f'printf("{s} %zu\\n", sizeof({s}));' for s in structs)
     src.write_text(f'#include <stdio.h>\n#include "{ROOT}/include/gdpt.h"\nint main(){{{body} return 0;}}\n')
     exe = tmp_path / "sz"

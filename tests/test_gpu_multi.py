@@ -1,0 +1,102 @@
+"""The tile loop sharded over several devices behind the C ABI (gdpt_multi_*, csrc/hip/multi_gpu.hip) and bench.py's
+N>1 step, on the ONE GPU a test box has:
+
+  * device set {0} over RCCL: communicator, streams, band bookkeeping, solve on devices[0];
+  * device sets {0,0} and {0,0,0} with the peer-copy transport (the only one that takes a device twice): two equal
+    bands / three ragged bands with a real halo row and a real gather — the indexing RCCL's in-place all-gather uses;
+  * `lajolla --devices 0,0 --exchange peer`;
+  * `bench.py --gpus 2 --dist-backend gloo`: the launcher, two rank processes sharing the GPU, the sharded step with
+    the HIP kernels, exchange staged through host memory.
+Every result must equal the single-device one bit for bit (same per-sample streams, same per-pixel summation order).
+What stays unverified on a one-GPU box: RCCL send/recv/all-gather between distinct devices (the driver's 8-GPU run)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, scene_variant
+
+BUFS = ("img", "cx0", "cy0", "cx1", "cy1")
+
+
+def test_band_rows_of_the_c_host_equal_the_python_mirror(G):
+    from gdpt_amd import sharding
+    for height in (1, 15, 16, 17, 64, 80, 512, 720, 1024, 1279):
+        for n in (1, 2, 3, 4, 7, 8, 16):
+            bands = [G.band_rows(height, n, b) for b in range(n)]
+            assert bands == sharding.all_bands(height, n), (height, n)
+            assert bands[0][0] == 0 and bands[-1][1] == height
+            for a, b in zip(bands, bands[1:]):
+                assert a[1] == b[0] and a[0] % 16 == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,exchange,height", [((0,), "rccl", 64), ((0,), "peer", 64), ((0, 0), "peer", 64),
+                                                     ((0, 0, 0), "peer", 80), ((0, 0, 0, 0), "peer", 48)])
+def test_multi_device_set_equals_single_device(G, scene_tmp, devices, exchange, height):
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=72, height=height)
+    sd = G.parse_scene(xml)
+    want_out, want, wrs, _ = G.Scene(sd).gradient_path_render(6, G.RNG_SAMPLE, return_buffers=True)
+    ms = G.MultiScene(sd, devices, exchange=G.EXCHANGE_RCCL if exchange == "rccl" else G.EXCHANGE_PEER_COPY)
+    for _ in range(2):                                    # twice: no stale state between calls
+        out, bufs, rs, st = ms.gradient_path_render(6, G.RNG_SAMPLE, return_buffers=True)
+        assert np.array_equal(out, want_out)
+        for k in BUFS:
+            assert np.array_equal(bufs[k], want[k]), k
+        assert rs.rays == wrs.rays and rs.bounces == wrs.bounces and rs.samples == wrs.samples
+    assert st.num_devices == len(devices)
+    assert [(st.row_begin[i], st.row_end[i]) for i in range(len(devices))] == [G.band_rows(height, len(devices), i) for i in range(len(devices))]
+    assert st.solve_ms > 0 and st.render_ms_max > 0 and st.wall_ms > 0
+
+
+@pytest.mark.gpu
+def test_multi_rejects_bad_device_sets(G, scene_tmp):
+    sd = G.parse_scene(scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=32, height=32))
+    with pytest.raises(G.GdptError, match="visible"):
+        G.MultiScene(sd, (0, 99))
+    with pytest.raises(G.GdptError, match="distinct"):
+        G.MultiScene(sd, (0, 0), exchange=G.EXCHANGE_RCCL)
+    with pytest.raises(G.GdptError):
+        G.MultiScene(sd, ())
+
+
+@pytest.mark.gpu
+def test_cli_row_bands(G, scene_tmp, tmp_path):
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=64, height=64)
+    exe = os.path.join(ROOT, "gradient-based-path-tracing_amd", "lajolla")
+    one, two = tmp_path / "one.pfm", tmp_path / "two.pfm"
+    r1 = subprocess.run([exe, "-o", str(one), "--spp", "4", xml], capture_output=True, text=True, timeout=300)
+    r2 = subprocess.run([exe, "-o", str(two), "--spp", "4", "--devices", "0,0", "--exchange", "peer", xml], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0 and r2.returncode == 0, r1.stderr + r2.stderr
+    assert "2 row bands (peer copies)" in r2.stdout
+    assert one.read_bytes() == two.read_bytes()
+    r3 = subprocess.run([exe, "--gpus", "64", xml], capture_output=True, text=True)
+    assert r3.returncode != 0
+
+
+def _bench(*extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--spp", "4", "--strong-spp", "8",
+           "--no-pmc", "--no-cpu-baseline"] + list(extra)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_equals_one_rank(G):
+    """`python bench.py --gpus 2` as typed (self-launching), both ranks on this box's one GPU over gloo: same strong-scaling
+    image as the single-rank run, hash for hash."""
+    one = _bench()
+    two = _bench("--gpus", "2", "--dist-backend", "gloo")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and "rehearsal" in two and "rehearsal" not in one
+    assert two["scaling"] == "weak" and two["config"]["workload"].count("8 spp total")
+    assert one["scaling_strong"]["out_sha1"] == two["scaling_strong"]["out_sha1"]
+    assert two["value"] > 0 and two["exchange_ms"] > 0
+    # and N=2 over RCCL on a one-GPU node is refused with a message, not a line
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "needs 2 GPUs" in r.stderr and not r.stdout.strip()
