@@ -30,7 +30,7 @@ def test_band_rows_of_the_c_host_equal_the_python_mirror(G):
             assert bands == sharding.all_bands(height, n), (height, n)
             assert bands[0][0] == 0 and bands[-1][1] == height
             for a, b in zip(bands, bands[1:]):
-                assert a[1] == b[0] and a[0] % 16 == 0
+                assert a[1] == b[0] and (a[0] % 16 == 0 or a[0] == a[1] == height)      # bands without rows sit at the end
 
 
 @pytest.mark.gpu
