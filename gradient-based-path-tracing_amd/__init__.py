@@ -77,6 +77,8 @@ def lib():
                                                       C.POINTER(defs.GdptRenderStats), C.POINTER(defs.GdptMultiStats)]
         L.gdpt_debug_knob_set.argtypes = [C.c_char_p, C.c_double]
         L.gdpt_debug_knobs_reset.restype = None
+        L.gdpt_debug_get_stamps.argtypes = [C.POINTER(C.c_double)]
+        L.gdpt_debug_get_stamps.restype = None
         _LIB = L
     return _LIB
 
@@ -357,11 +359,18 @@ class debug_knobs:
         lib().gdpt_debug_knobs_reset()
 
     @staticmethod
+    def stamps():
+        """Per-segment wave cycles of the last render made under debug_knobs(stamps=1) (include/gdpt_debug.h)."""
+        v = (C.c_double * 8)()
+        lib().gdpt_debug_get_stamps(v)
+        return dict(zip(("queue", "trace", "vertex", "consume", "bsdf", "finish", "camera", "wave_steps"), list(v)))
+
+    @staticmethod
     def from_env(environ=None):
         """GDPT_FORCE_EAGER=1 -> force_eager=1 ... for the manual sweep scripts (tests/sweep_*.py, tune_render.py)."""
         environ = os.environ if environ is None else environ
         names = ("force_eager", "log2k", "keep_frac", "search_frac", "blocks_per_cu", "no_lds_scene", "lds_wide",
-                 "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor")
+                 "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "stamps")
         lib().gdpt_debug_knobs_reset()
         for n in names:
             v = environ.get("GDPT_" + n.upper())

@@ -13,6 +13,7 @@ void set_last_error(const std::string &msg);
 // Test-only overrides (include/gdpt_debug.h): value of knob `name`, or `def` when no test has set it. The table is
 // empty in every product run; no environment variable feeds it.
 double debug_knob(const char *name, double def);
+void debug_store_stamps(const unsigned long long *v, int n);   // diagnostic kernel's segment cycles -> gdpt_debug_get_stamps
 inline int debug_knob_int(const char *name, int def) { return (int)debug_knob(name, (double)def); }
 
 template <class F>

@@ -423,6 +423,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.force_log2k = env_int("log2k", -1);
     rl.num_cus = sc->num_cus;
     rl.blocks_per_cu = env_int("blocks_per_cu", 0);
+    rl.stamped = env_int("stamps", 0) != 0;
     {
         size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, b.spp, rl.force_log2k);
         if (need > sc->partials_doubles) {
@@ -464,6 +465,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
         stats->render_ms = ms;
         stats->wave_node_trips = sc->h_counters->wave_node_trips; stats->wave_leaf_trips = sc->h_counters->wave_leaf_trips;
         stats->wave_steps = sc->h_counters->wave_steps; stats->lane_steps = sc->h_counters->lane_steps;
+        if (rl.stamped) gdpt::debug_store_stamps(sc->h_counters->stamps, 8);
         // only the persistent kernel over an LDS-resident scene can still walk the BVH2 form
         const bool lds_kernel = rl.one_sided_materials && !rl.force_eager && b.rng == GDPT_RNG_SAMPLE && rl.scene_fits_lds;
         stats->node_bytes = (lds_kernel && !rl.lds_wide) ? sizeof(DevBvhNode) : sizeof(DevBvh4Node);

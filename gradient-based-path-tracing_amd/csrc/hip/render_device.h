@@ -41,6 +41,26 @@ constexpr int kLdsSceneBytes = 20 * 1024;     // nodes + prims + shading table +
 constexpr int kLdsSceneLevels = 12;           // stack slots per lane when the scene is LDS-resident
 
 struct LaneCounters { unsigned rays, bounces, nonfinite; };
+
+// Diagnostic builds only (render_phases_diag.hip, selected by the test-only knob "stamps", include/gdpt_debug.h): where a
+// wave's cycles go, segment by segment. s_memtime is read by the wave (scalar), so a segment's share includes what the
+// lanes that sit it out wait for — the point of the exercise. The product kernels are built with ON = false: every call
+// below compiles to nothing. Stamp values only ever reach RenderCounters::stamps, never an output image.
+enum { SEG_QUEUE = 0, SEG_TRACE = 1, SEG_VERTEX = 2, SEG_CONSUME = 3, SEG_BSDF = 4, SEG_FINISH = 5, SEG_CAMERA = 6, SEG_STEPS = 7, SEG_COUNT = 8 };
+template <bool ON> struct Stamps {
+    unsigned long long last, acc[SEG_COUNT];
+    GD void start() { if (ON) { for (int i = 0; i < SEG_COUNT; i++) acc[i] = 0; last = __builtin_amdgcn_s_memtime(); } }
+    GD void mark(int seg) {                       // time since the previous mark belongs to `seg`
+        if (ON) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the stamp has landed
+            acc[seg] += t - last; last = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    GD void tick(int seg) { if (ON) acc[seg] += 1; }
+};
 struct Accum { D3 r, dx0, dy0, dx1, dy1; };
 
 struct KernelArgs {
@@ -391,9 +411,10 @@ struct Lane {
 
 // SERIAL_RNG: one PCG stream runs through consecutive samples (TILE scheme); otherwise each sample owns stream
 // `base + s` (SAMPLE scheme) and its sub-pixel / bounce-1 numbers are re-derived from it when an offset needs them.
-template <bool LAMBERT, bool SERIAL_RNG, class ACC>
+template <bool LAMBERT, bool SERIAL_RNG, class ACC, class STAMPS = Stamps<false>>
 GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, double spp, int x, int y, unsigned long long base,
-                  Lane &L, Trav &tv, LanePriv &lp, ACC &acc, LaneCounters &lc, TraceCounters &tc) {
+                  Lane &L, Trav &tv, LanePriv &lp, ACC &acc, LaneCounters &lc, TraceCounters &tc, STAMPS *stp = nullptr) {
+    STAMPS none; STAMPS &stamps = stp ? *stp : none;
     const DevCamera &cam = sv.cam;
     const int w = cam.width, h = cam.height;
     const int st0 = L.st;
@@ -410,6 +431,7 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
         hit = tv.best.gid >= 0;
         if (hit) make_vertex(sv, tx.tris, tx.need_uv, ray, tv.best, 0.0, (st0 == S_BOUNCE) ? 0.0 : 0.25 / (double)max(w, h), nv);   // src/ray.h:33-35, :564
     }
+    stamps.mark(SEG_VERTEX);
     // ---------------- consume the hit ----------------
     if (st0 == S_START) {
         act = ACT_PRIMARY_RAY;
@@ -460,6 +482,7 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
         else { acc_no_offsets(acc, lp.radiance(), L.contrib, L.prob, spp, lc); act = ACT_NEXT_SAMPLE; }
         // (one-sided lobes: offsets alive after bounce 1 are retired by bounce 2's re-sampling, see file header)
     }
+    stamps.mark(SEG_CONSUME);
     // ---------------- shared BSDF block: sample a direction at `nv` and evaluate f / pdf there ----------------
     // Needed by (a) base lanes that start a bounce iteration at nv and (b) offset lanes whose vertex nv is re-sampled
     // with the base path's bounce-1 numbers (:773-959). One copy of the code, run by both groups together.
@@ -487,6 +510,7 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
         sampled = mat_sample<LAMBERT>(sv, tx, nv, dir_view, ruv, rw, bs);
         if (sampled) mat_eval_pdf<LAMBERT>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
     }
+    stamps.mark(SEG_BSDF);
     if (st0 == S_OFFSET) {
         const int k = L.k();
         D3 cX = splat(0);
@@ -517,6 +541,7 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
             }
         }
     }
+    stamps.mark(SEG_FINISH);
     if (act == ACT_OFFSETS) { L.kc &= ~3; act = ACT_OFFSET_RAY; }
     if (act == ACT_NEXT_SAMPLE) {
         L.s++;
@@ -547,6 +572,7 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
         L.org = r.org; L.dir = r.dir;
     }
     if (L.st != S_DONE) trav_init(sv, tv, __builtin_huge_val());      // every surviving lane now holds a fresh pending ray
+    stamps.mark(SEG_CAMERA);
 }
 
 // The lane machine's two halves. trace_pending: traversal of the wave's unfinished pending rays, left when at most
@@ -695,7 +721,7 @@ struct WaveQueue {
 // that finishes early picks up the next item instead of idling behind the longest path of its wave. Per-item sums go
 // to `partials` ([15][items], one writer per slot) and are merged per pixel in chunk order by gdpt_reduce_partials,
 // so the result does not depend on which lane processed what, or when.
-template <bool LAMBERT, bool LDS_SCENE, bool WIDE, bool WW>
+template <bool LAMBERT, bool LDS_SCENE, bool WIDE, bool WW, bool STAMPED = false>
 __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv, KernelArgs a) {
     constexpr int kLevels = LDS_SCENE ? kLdsSceneLevels : GDPT_BVH_MAX_DEPTH;
     __shared__ int s_stack[kLevels * kBlock];
@@ -721,6 +747,8 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
     unsigned long long base = 0;
     long long my_item = -1;
     WaveQueue wq;
+    Stamps<STAMPED> stamps;
+    stamps.start();
     for (;;) {
         // ---- hand out work to idle lanes
         const bool idle = (L.st == S_DONE);
@@ -744,13 +772,18 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
             L.st = (inside && s0 < s1) ? S_START : S_DONE;
         }
         if (!__any(L.st != S_DONE)) { if (wq.exhausted) break; else continue; }
+        stamps.mark(SEG_QUEUE);
         trace_pending<TraceCfg<WW, WIDE, !LDS_SCENE>>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
+        stamps.mark(SEG_TRACE);
+        stamps.tick(SEG_STEPS);
         if (lane_ready(L, tv)) {
             if (tx.count) { tc.lane_steps++; if (wave_leader()) tc.wave_steps++; }
-            lane_step<LAMBERT, false>(sv, tx, a.max_depth, spp, x, y, base, L, tv, lp, acc, lc, tc);
+            lane_step<LAMBERT, false, AccLds, Stamps<STAMPED>>(sv, tx, a.max_depth, spp, x, y, base, L, tv, lp, acc, lc, tc, &stamps);
         }
     }
     flush_counters(a, lc, tc, a.count != 0);
+    if (STAMPED && (tid & 63) == 0)
+        for (int i = 0; i < SEG_COUNT; i++) atomicAdd(&a.counters->stamps[i], stamps.acc[i]);
 }
 
 #ifdef GDPT_BUILD_REDUCE   // emitted by render_phases_lambert.hip only (non-template kernel)
@@ -992,6 +1025,7 @@ __global__ __launch_bounds__(64) void gdpt_render_tile_stream_eager(DevSceneView
 namespace gdpt {
 // host launchers, one translation unit per kernel family (parallel compilation)
 void launch_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lds_wide, hipStream_t stream);
+void launch_phases_lambert_stamped(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, hipStream_t stream);   // diagnostic build
 void launch_reduce_partials(const DevSceneView &sv, const gd::KernelArgs &a, hipStream_t stream);
 void launch_phases_general(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lds_wide, hipStream_t stream);
 void launch_phases_twosided(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, void *bounce_log, hipStream_t stream);

@@ -8,6 +8,7 @@ namespace gdpt {
 struct RenderCounters {            // device-resident, zeroed per render
     unsigned long long rays, bounces, nonfinite, nodes, prims;
     unsigned long long wave_node_trips, wave_leaf_trips, wave_steps, lane_steps;   // counting builds: SIMT utilisation
+    unsigned long long stamps[8];  // diagnostic build (knob "stamps"): wave cycles per segment, render_device.h SEG_*
 };
 
 struct RenderLaunch {
@@ -32,6 +33,7 @@ struct RenderLaunch {
     size_t bounce_log_bytes;
     int num_cus;                   // compute units of the device (persistent grid size)
     int blocks_per_cu;             // persistent blocks per CU (0 = default 2)
+    bool stamped;                  // diagnostic build with in-kernel cycle stamps (test-only knob "stamps")
     double *partials;              // device, >= 15 * W * rows * 8 doubles (work-item partial sums)
     unsigned long long *queue_head;// device, work-queue head
 };

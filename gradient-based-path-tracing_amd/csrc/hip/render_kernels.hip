@@ -72,7 +72,8 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
             if (rl.two_sided_machine) {
                 if (!rl.bounce_log || rl.bounce_log_bytes < twosided_log_bytes(blocks)) throw std::runtime_error("launch_render: bounce log missing");
                 launch_phases_twosided(sv, a, grid, rl.scene_fits_lds && rl.lds_wide, rl.bounce_log, stream);
-            } else if (rl.lambert_only) launch_phases_lambert(sv, a, grid, rl.scene_fits_lds, rl.lds_wide, stream);
+            } else if (rl.lambert_only && rl.stamped && (!rl.scene_fits_lds || rl.lds_wide)) launch_phases_lambert_stamped(sv, a, grid, rl.scene_fits_lds, stream);
+            else if (rl.lambert_only) launch_phases_lambert(sv, a, grid, rl.scene_fits_lds, rl.lds_wide, stream);
             else launch_phases_general(sv, a, grid, rl.scene_fits_lds, rl.lds_wide, stream);
             launch_reduce_partials(sv, a, stream);
         }

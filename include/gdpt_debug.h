@@ -21,6 +21,8 @@
  *   presplit_floor       (real) pre-split priority floor (scene upload)
  *   bvh_leaf_max         (1..4) SAH builder: primitives per leaf (scene upload)
  *   bvh_leaf_factor      (real) SAH builder: leaf cost factor (scene upload)
+ *   stamps               (0/1)  Lambertian lane machine: the diagnostic build with in-kernel cycle stamps; a render with
+ *                               stats then leaves its per-segment wave cycles for gdpt_debug_get_stamps
  */
 #ifndef GDPT_DEBUG_H
 #define GDPT_DEBUG_H
@@ -30,6 +32,9 @@ extern "C" {
 
 /* Sets one override; returns 0, or non-zero (message in gdpt_last_error) for an unknown name. */
 int gdpt_debug_knob_set(const char *name, double value);
+/* Wave cycles per segment of the last stamped render (summed over waves): [0] work queue, [1] traversal,
+ * [2] hit-vertex rebuild, [3] state arms, [4] BSDF block, [5] offset / finish arm, [6] camera-ray block, [7] wave steps. */
+void gdpt_debug_get_stamps(double out[8]);
 /* Removes every override: the library is back on its product path. */
 void gdpt_debug_knobs_reset(void);
 

@@ -66,7 +66,8 @@ def test_baseline_config_at_its_own_size(G, O, scene_tmp, name, rel, film, integ
     ref = O.fourier_solve(c, cx, cy, 0.04)
     assert rel_l2(out, ref) < 1e-10
     wgt = weights(W, H)
-    np.testing.assert_allclose((wgt * out).sum(axis=(0, 1)), (wgt * c).sum(axis=(0, 1)), rtol=1e-10, atol=1e-9)
+    # (absolute slack scaled by the magnitude summed: the Disney primal is exactly zero while the gradients are not)
+    np.testing.assert_allclose((wgt * out).sum(axis=(0, 1)), (wgt * c).sum(axis=(0, 1)), rtol=1e-10, atol=1e-11 * float(np.abs(wgt * out).sum()))
     # a 16-row band (one tile row, mid image) against the oracle
     r0 = (H // 2) // 16 * 16
     ob, ost = O.OracleScene(sd.ptr, use_bvh=True).render(spp, G.RNG_SAMPLE, rows=(r0, r0 + 16), threads=os.cpu_count())
