@@ -41,21 +41,26 @@ GD bool tri_hit(const float o[3], const float d[3], float tnear, float tfar, con
 
 // Sphere primitive: fp64 quadratic on the fp32 ray (src/shapes/sphere.inl:15-106).
 // Kept out of line: spheres are rare (an emitter or two), and inlining this fp64 block into the traversal loop would
-// raise the register pressure of every triangle-only ray.
-__device__ __noinline__ bool sphere_hit(const float *o, const float *d, float tnear, float tfar, const DevSphere &sp, Hit &h) {
+// raise the register pressure of every triangle-only ray. Arguments and result travel BY VALUE (registers): pointer
+// parameters would force the caller's ray arrays into scratch memory, with a scratch store per traced ray in every
+// scene, spheres or not, and a vmcnt(0) wait behind them wherever the compiler has to protect the stored registers.
+struct SphereHit { float t, u, v, ngx, ngy, ngz; int ok; };
+__device__ __noinline__ SphereHit sphere_hit(float o0, float o1, float o2, float d0, float d1, float d2, float tnear, float tfar,
+                                             double cx, double cyc, double cz, double radius) {
 #pragma clang fp contract(off)
-    double ox = o[0] - sp.center[0], oy = o[1] - sp.center[1], oz = o[2] - sp.center[2];
-    double dx = d[0], dy = d[1], dz = d[2];
+    SphereHit h; h.ok = 0; h.t = h.u = h.v = h.ngx = h.ngy = h.ngz = 0.0f;
+    double ox = o0 - cx, oy = o1 - cyc, oz = o2 - cz;
+    double dx = d0, dy = d1, dz = d2;
     double A = dx * dx + dy * dy + dz * dz;
     double B = 2 * (dx * ox + dy * oy + dz * oz);
-    double C = (ox * ox + oy * oy + oz * oz) - sp.radius * sp.radius;
+    double C = (ox * ox + oy * oy + oz * oz) - radius * radius;
     double t0, t1;
     if (A == 0) {
-        if (B == 0) return false;
+        if (B == 0) return h;
         t0 = t1 = -C / B;
     } else {
         double disc = B * B - 4 * A * C;
-        if (disc < 0) return false;
+        if (disc < 0) return h;
         double rd = sqrt(disc);
         if (B >= 0) { t0 = (-B - rd) / (2 * A); t1 = 2 * C / (-B - rd); }
         else { t0 = 2 * C / (-B + rd); t1 = (-B + rd) / (2 * A); }
@@ -64,16 +69,17 @@ __device__ __noinline__ bool sphere_hit(const float *o, const float *d, float tn
     double rn = tnear, rf = tfar, t = -1;
     if (t0 >= rn && t0 < rf) t = t0;
     if (t1 >= rn && t1 < rf && t < 0) t = t1;
-    if (!(t >= rn && t < rf)) return false;
-    double gx = ((double)o[0] + t * dx) - sp.center[0], gy = ((double)o[1] + t * dy) - sp.center[1], gz = ((double)o[2] + t * dz) - sp.center[2];
-    double inv_r = 1.0 / sp.radius;
+    if (!(t >= rn && t < rf)) return h;
+    double gx = ((double)o0 + t * dx) - cx, gy = ((double)o1 + t * dy) - cyc, gz = ((double)o2 + t * dz) - cz;
+    double inv_r = 1.0 / radius;
     double cy = fmin(fmax(gy * inv_r, -1.0), 1.0);
     double elevation = acos(cy);
     double azimuth = atan2(gz * inv_r, gx * inv_r);
     h.ngx = (float)gx; h.ngy = (float)gy; h.ngz = (float)gz;
     h.u = (float)(azimuth / kTwoPi); h.v = (float)(elevation / kPi);
     h.t = (float)t;
-    return true;
+    h.ok = 1;
+    return h;
 }
 
 GD void test_prim(const DevSceneView &sv, const DevPrim &pr, const float o[3], const float d[3], float tnear, float tfar, Hit &best) {
@@ -84,12 +90,12 @@ GD void test_prim(const DevSceneView &sv, const DevPrim &pr, const float o[3], c
         if (best.gid >= 0 && !(t < best.t || (t == best.t && (int)gid < best.gid))) return;
         best.t = t; best.u = u; best.v = v; best.gid = (int)gid;   // Ng: per-triangle constant, see DevTriShade::gn
     } else {
-        Hit h;
-        if (!sphere_hit(o, d, tnear, tfar, sv.spheres[gid & ~GDPT_SPHERE_FLAG], h)) return;
+        const DevSphere &sp = sv.spheres[gid & ~GDPT_SPHERE_FLAG];
+        const SphereHit sh = sphere_hit(o[0], o[1], o[2], d[0], d[1], d[2], tnear, tfar, sp.center[0], sp.center[1], sp.center[2], sp.radius);
+        if (!sh.ok) return;
         int sg = sv.num_tris + (int)(gid & ~GDPT_SPHERE_FLAG);   // spheres order after all triangles
-        if (best.gid >= 0 && !(h.t < best.t || (h.t == best.t && sg < best.gid))) return;
-        h.gid = sg;
-        best = h;
+        if (best.gid >= 0 && !(sh.t < best.t || (sh.t == best.t && sg < best.gid))) return;
+        best.t = sh.t; best.u = sh.u; best.v = sh.v; best.ngx = sh.ngx; best.ngy = sh.ngy; best.ngz = sh.ngz; best.gid = sg;
     }
 }
 
