@@ -401,15 +401,17 @@ def _find(table, name):
     return None
 
 
-def _log2_chunks(spp, pixels):
-    """Work items per pixel of the persistent render kernel (render_log2_chunks, csrc/hip/render_kernels.hip)."""
-    by_spp = 0
-    while (8 << by_spp) <= spp:
-        by_spp += 1
-    target = 0
-    while target < 8 and (pixels << target) < (1 << 20):
-        target += 1
-    return min(by_spp, max(target, 3))
+def _num_chunks(spp, pixels, lanes=256 * 2 * 256):
+    """Work items per pixel of the persistent render kernel (make_chunk_plan, csrc/hip/render_kernels.hip)."""
+    cap = max(1, spp * pixels // (lanes * 4))
+    rem, n = spp, 0
+    while rem > 0:
+        sz = min(max(1, (rem * 2 + 4) // 5), cap)
+        if n == 63:
+            sz = rem
+        rem -= sz
+        n += 1
+    return n
 
 
 def _kernel_lines(got, W, H, spp, pmc):
@@ -426,7 +428,7 @@ def _kernel_lines(got, W, H, spp, pmc):
         lines.append({"kernel": label, "launches_per_step": per_step, "avg_us": t["avg_us"], "bound": "hbm", "achieved": ach,
                       "peak": pmc.HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / pmc.HBM_PEAK_GBS, "algorithmic_bytes": work,
                       "traffic": pmc.hbm_bytes(_find(got["counters"], pattern) or {})})
-    items = (((W + 15) // 16) * ((H + 15) // 16) * 256) << _log2_chunks(spp, W * H)
+    items = ((W + 15) // 16) * ((H + 15) // 16) * 256 * _num_chunks(spp, W * H)
     add("gdpt_reduce_partials", "gd::gdpt_reduce_partials", items * 128.0 + 5 * n3 * 8.0)   # 128-B record per work item in, five images out
     add("assemble_kernel", "gp::assemble_kernel", 8 * 8.0 * n3)            # 5 reads + 3 writes per unknown
     add("dct_rhs_kernel", "gp::dct_rhs_kernel", 4 * 8.0 * n3)              # read c, cx, cy; write h

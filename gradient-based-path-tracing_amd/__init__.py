@@ -361,9 +361,9 @@ class debug_knobs:
     @staticmethod
     def stamps():
         """Per-segment wave cycles of the last render made under debug_knobs(stamps=1) (include/gdpt_debug.h)."""
-        v = (C.c_double * 8)()
+        v = (C.c_double * 12)()
         lib().gdpt_debug_get_stamps(v)
-        return dict(zip(("queue", "trace", "vertex", "consume", "bsdf", "finish", "camera", "wave_steps"), list(v)))
+        return dict(zip(("loop_head", "trace", "vertex", "consume", "bsdf", "finish", "camera", "wave_steps", "publish", "take", "item"), list(v)))
 
     @staticmethod
     def from_env(environ=None):

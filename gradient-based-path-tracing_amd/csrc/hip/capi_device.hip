@@ -425,7 +425,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.blocks_per_cu = env_int("blocks_per_cu", 0);
     rl.stamped = env_int("stamps", 0) != 0;
     {
-        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, b.spp, rl.force_log2k);
+        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, b.spp, rl.force_log2k, (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256);
         if (need > sc->partials_doubles) {
             if (sc->d_partials) { ck(hipStreamSynchronize(stream), "hipStreamSynchronize"); hipFree(sc->d_partials); sc->d_partials = nullptr; }
             ck(hipMalloc((void **)&sc->d_partials, need * sizeof(double)), "hipMalloc(work-item partials)");
@@ -438,7 +438,8 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.two_sided_machine = !sc->one_sided && !sc->has_rough && !rl.force_eager && b.rng == GDPT_RNG_SAMPLE && !env_int("no_twosided_machine", 0);
     if (rl.two_sided_machine) {
         const long long tiles = (long long)((sc->view.cam.width + 15) / 16) * ((b.row_end - b.row_begin + 15) / 16);
-        const long long items = (tiles * 256) << gdpt::render_log2_chunks(b.spp, rl.force_log2k, (long long)sc->view.cam.width * (b.row_end - b.row_begin));
+        const long long items = (tiles * 256) * gdpt::make_chunk_plan(b.spp, rl.force_log2k, (long long)sc->view.cam.width * (b.row_end - b.row_begin),
+                                                                      (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256).n;
         const size_t need = gdpt::twosided_log_bytes(gdpt::persistent_blocks(rl, items));
         if (need > sc->bounce_log_bytes) {
             if (sc->d_bounce_log) { ck(hipStreamSynchronize(stream), "hipStreamSynchronize"); hipFree(sc->d_bounce_log); sc->d_bounce_log = nullptr; }
@@ -465,7 +466,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
         stats->render_ms = ms;
         stats->wave_node_trips = sc->h_counters->wave_node_trips; stats->wave_leaf_trips = sc->h_counters->wave_leaf_trips;
         stats->wave_steps = sc->h_counters->wave_steps; stats->lane_steps = sc->h_counters->lane_steps;
-        if (rl.stamped) gdpt::debug_store_stamps(sc->h_counters->stamps, 8);
+        if (rl.stamped) gdpt::debug_store_stamps(sc->h_counters->stamps, 12);
         // only the persistent kernel over an LDS-resident scene can still walk the BVH2 form
         const bool lds_kernel = rl.one_sided_materials && !rl.force_eager && b.rng == GDPT_RNG_SAMPLE && rl.scene_fits_lds;
         stats->node_bytes = (lds_kernel && !rl.lds_wide) ? sizeof(DevBvhNode) : sizeof(DevBvh4Node);
@@ -498,7 +499,7 @@ void path_render_device_impl(GdptScene *sc, const GdptRenderParams *params, doub
     rl.scene_fits_lds = !env_int("no_lds_scene", 0) &&
                         gdpt::scene_fits_lds_wide(sc->view.num_nodes4, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->wide_stack_need);
     {
-        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, b.spp, rl.force_log2k);
+        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, b.spp, rl.force_log2k, (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256);
         if (need > sc->partials_doubles) {
             if (sc->d_partials) { ck(hipStreamSynchronize(stream), "hipStreamSynchronize"); hipFree(sc->d_partials); sc->d_partials = nullptr; }
             ck(hipMalloc((void **)&sc->d_partials, need * sizeof(double)), "hipMalloc(work-item partials)");

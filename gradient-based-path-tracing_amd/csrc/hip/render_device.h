@@ -46,7 +46,7 @@ struct LaneCounters { unsigned rays, bounces, nonfinite; };
 // wave's cycles go, segment by segment. s_memtime is read by the wave (scalar), so a segment's share includes what the
 // lanes that sit it out wait for — the point of the exercise. The product kernels are built with ON = false: every call
 // below compiles to nothing. Stamp values only ever reach RenderCounters::stamps, never an output image.
-enum { SEG_QUEUE = 0, SEG_TRACE = 1, SEG_VERTEX = 2, SEG_CONSUME = 3, SEG_BSDF = 4, SEG_FINISH = 5, SEG_CAMERA = 6, SEG_STEPS = 7, SEG_COUNT = 8 };
+enum { SEG_QUEUE = 0, SEG_TRACE = 1, SEG_VERTEX = 2, SEG_CONSUME = 3, SEG_BSDF = 4, SEG_FINISH = 5, SEG_CAMERA = 6, SEG_STEPS = 7, SEG_PUBLISH = 8, SEG_TAKE = 9, SEG_ITEM = 10, SEG_COUNT = 12 };
 template <bool ON> struct Stamps {
     unsigned long long last, acc[SEG_COUNT];
     GD void start() { if (ON) { for (int i = 0; i < SEG_COUNT; i++) acc[i] = 0; last = __builtin_amdgcn_s_memtime(); } }
@@ -67,9 +67,12 @@ struct KernelArgs {
     int spp, log2k, tile_w, tile_h, tiles_x;
     int row_begin, row_end, max_depth;
     int thresh_a, thresh_c;
-    int count, log2c;                  // 2^log2c work items (chunks of the sample range) per pixel
-    long long num_items;               // tiles of the band * 256 * chunks (< 2^32)
+    int count;
+    int num_chunks;                    // work items per pixel: chunk c covers samples [chunk_begin[c], chunk_begin[c+1])
+    long long num_slots;               // pixel slots of the band: tiles * 256 (ragged edge tiles keep all 256)
+    long long num_items;               // num_slots * num_chunks (< 2^32); item = chunk * num_slots + slot ("tier-major")
     double *partials;                  // [num_items][16]: 15 sums (r, dx0, dy0, dx1, dy1 as xyz) + pad, 128-B records
+    int chunk_begin[gdpt::kMaxChunks + 1];
     unsigned long long *queue_head;    // work-queue head (zeroed per launch)
     double *img, *cx0, *cy0, *cx1, *cy1;
     gdpt::RenderCounters *counters;
@@ -669,23 +672,29 @@ GD TraceCtx setup_trace(const DevSceneView &sv, unsigned char *s_scene, int *s_s
     return tx;
 }
 
-// Work items of the persistent kernel: item = ((tile * 256 + pixel_in_tile) << log2c) + chunk, tiles = the reference's
-// 16x16 tiles of the band in row-major order (ragged edge tiles keep all 256 slots; their outside pixels are empty
-// items), so a wave's batch of 64 consecutive items covers neighbouring pixels and the mapping needs one 32-bit
-// division. Returns false for an empty slot.
+// Work items of the persistent kernels: item = chunk * num_slots + slot, slot = tile * 256 + pixel_in_tile, tiles = the
+// reference's 16x16 tiles of the band in row-major order (ragged edge tiles keep all 256 slots; their outside pixels
+// are empty items). A wave's batch of 64 consecutive items covers 64 neighbouring pixels (a 16x4 quarter tile) of one
+// chunk. Chunks are handed out chunk-major and get SHORTER along the queue (render_kernels.hip: make_chunk_plan), so the
+// items still in flight when the queue runs dry are single samples: the kernel's drain is one short sample long
+// instead of one long item (measured: 0.44 ms -> see DESIGN.md 4.1). One 32-bit division per started item for the
+// chunk, one for the tile row. Returns false for an empty slot.
 GD bool item_to_pixel(const KernelArgs &a, int W, unsigned item, int &x, int &y, int &s0, int &s1) {
-    const unsigned c = item & ((1u << a.log2c) - 1u), pt = item >> a.log2c;
+    const unsigned c = item / (unsigned)a.num_slots, pt = item - c * (unsigned)a.num_slots;
     const unsigned pin = pt & 255u, tile = pt >> 8;
     const unsigned ty = tile / (unsigned)a.tiles_x, tx = tile - ty * (unsigned)a.tiles_x;
     x = (int)(tx * 16u + (pin & 15u)); y = a.row_begin + (int)(ty * 16u + (pin >> 4));
-    s0 = (int)(((long long)c * a.spp) >> a.log2c); s1 = (int)(((long long)(c + 1u) * a.spp) >> a.log2c);
+    s0 = a.chunk_begin[c]; s1 = a.chunk_begin[c + 1];
     return x < W && y < a.row_end;
 }
 
 // A wave's view of the global work queue. Every lane of the wave calls take(); idle lanes may receive an item index.
-// Slices are fetched with one atomicAdd per refill: 64 items while plenty are left; towards the end only what the idle
-// lanes (and a fair share of the remainder) can start now, so that no wave sits on unstarted items while others have
-// run dry.
+// Slices are fetched with one returning atomicAdd per refill (a round trip to the L2 atomic unit: 2-3 k cycles of the
+// wave, measured with the stamped build): 64 items while at least one full slice per wave is left, i.e. for all but the
+// last waves*64 items; in that tail only what the idle lanes (and half a fair share of the remainder) can start now, so
+// that no wave sits on unstarted items while others have run dry. (Shrinking the slices from half-way through the
+// queue, as an earlier version did, made the second half of the kernel pay the round trip on almost every step:
+// 15 % of all wave cycles on cbox 512x512x16.)
 struct WaveQueue {
     long long next = 0, end = 0, seen_head = 0;
     bool exhausted = false;
@@ -695,9 +704,10 @@ struct WaveQueue {
         if (m_idle) {
             if (next >= end && !exhausted) {
                 const unsigned left = (unsigned)(a.num_items - seen_head);          // num_items < 2^32
-                long long want = (long long)(left / (gridDim.x * (unsigned)(kBlock / 64) * 4u));
+                const unsigned waves = gridDim.x * (unsigned)(kBlock / 64);
                 const long long n_idle_now = __popcll(m_idle);
-                want = want > 64 ? 64 : (want < n_idle_now ? n_idle_now : want);
+                long long want = 64;
+                if (left < waves * 64u) { want = (long long)(left / (waves * 2u)); want = want > 64 ? 64 : (want < n_idle_now ? n_idle_now : want); }
                 unsigned long long got = 0;
                 if ((tid & 63) == 0) got = atomicAdd(a.queue_head, (unsigned long long)want);
                 got = __shfl(got, 0, 64);
@@ -762,7 +772,9 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
             acc.init();
             my_item = -1;
         }
+        stamps.mark(SEG_PUBLISH);
         const long long got_item = wq.take(a, idle, tid);
+        stamps.mark(SEG_TAKE);
         if (got_item >= 0) {
             my_item = got_item;
             int s0, s1;
@@ -771,6 +783,7 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
             L.s = s0; L.s_end = s1;
             L.st = (inside && s0 < s1) ? S_START : S_DONE;
         }
+        stamps.mark(SEG_ITEM);
         if (!__any(L.st != S_DONE)) { if (wq.exhausted) break; else continue; }
         stamps.mark(SEG_QUEUE);
         trace_pending<TraceCfg<WW, WIDE, !LDS_SCENE>>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
@@ -789,18 +802,17 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
 #ifdef GDPT_BUILD_REDUCE   // emitted by render_phases_lambert.hip only (non-template kernel)
 // Sums the C per-chunk partials of every pixel in chunk order and writes the five images (one thread per pixel).
 __global__ __launch_bounds__(256) void gdpt_reduce_partials(KernelArgs a, int W) {
-    // 16 consecutive threads per pixel slot: thread j sums component j of the slot's 2^log2c records in chunk order
-    const long long nslots = a.num_items >> a.log2c;                     // pixel slots (tiles * 256)
+    // 16 consecutive threads per pixel slot: thread j sums component j of the slot's records in chunk order
+    const long long nslots = a.num_slots;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long idx = t >> 4;                                        // pixel slot in item order
+    const long long idx = t >> 4;                                        // pixel slot
     const int j = (int)(t & 15);
     if (idx >= nslots || j == 15) return;
     int x, y, s0, s1;
-    if (!item_to_pixel(a, W, (unsigned)(idx << a.log2c), x, y, s0, s1)) return;
-    const int chunks = 1 << a.log2c;
-    const double *src = a.partials + ((size_t)(idx << a.log2c)) * 16 + j;
+    if (!item_to_pixel(a, W, (unsigned)idx, x, y, s0, s1)) return;
+    const double *src = a.partials + (size_t)idx * 16 + j;
     double v = 0;
-    for (int c = 0; c < chunks; c++) v += src[(size_t)c * 16];
+    for (int c = 0; c < a.num_chunks; c++) v += src[(size_t)c * (size_t)nslots * 16];
     double *img = (j < 3) ? a.img : (j < 6) ? a.cx0 : (j < 9) ? a.cy0 : (j < 12) ? a.cx1 : a.cy1;
     img[((size_t)y * W + x) * 3 + (j % 3)] = v;
 }

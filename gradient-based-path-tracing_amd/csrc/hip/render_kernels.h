@@ -5,10 +5,14 @@
 
 namespace gdpt {
 
+// A pixel's samples are cut into work items ("chunks"): chunk c covers samples [begin[c], begin[c+1]).
+constexpr int kMaxChunks = 64;
+struct ChunkPlan { int n; int begin[kMaxChunks + 1]; };
+
 struct RenderCounters {            // device-resident, zeroed per render
     unsigned long long rays, bounces, nonfinite, nodes, prims;
     unsigned long long wave_node_trips, wave_leaf_trips, wave_steps, lane_steps;   // counting builds: SIMT utilisation
-    unsigned long long stamps[8];  // diagnostic build (knob "stamps"): wave cycles per segment, render_device.h SEG_*
+    unsigned long long stamps[12];  // diagnostic build (knob "stamps"): wave cycles per segment, render_device.h SEG_*
 };
 
 struct RenderLaunch {
@@ -44,8 +48,10 @@ bool scene_fits_lds_wide(int num_nodes4, int num_prims, int num_tris, int num_ma
 size_t twosided_log_bytes(unsigned blocks);
 unsigned persistent_blocks(const RenderLaunch &rl, long long num_items);
 void launch_path_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t stream);
-int render_log2_chunks(int spp, int force_log2k, long long pixels);
-size_t render_partials_doubles(int width, int rows, int spp, int force_log2k);
+// Chunk sizes shrink along the queue (about 40 % of what is left each time, ending in single samples) unless
+// force_log2k >= 0 asks for 2^k equal chunks (tests). `lanes` = resident lanes of the persistent grid.
+ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long lanes);
+size_t render_partials_doubles(int width, int rows, int spp, int force_log2k, long long lanes);
 
 // Enqueues the five-buffer render on `stream`. Throws std::runtime_error on a launch failure.
 void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t stream);

@@ -10,6 +10,18 @@ const char *render_kernel_name(int rng_scheme) {
     return rng_scheme == GDPT_RNG_TILE ? "gdpt_render_tile_stream_phases" : "gdpt_render_phases";
 }
 
+static long long resident_lanes(const RenderLaunch &rl) { return (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * gd::kBlock; }
+
+// item layout of the persistent kernels (render_device.h: item_to_pixel)
+static void set_chunks(gd::KernelArgs &a, const RenderLaunch &rl, int W, int rows) {
+    const ChunkPlan plan = make_chunk_plan(rl.spp, rl.force_log2k, (long long)W * rows, resident_lanes(rl));
+    a.num_chunks = plan.n;
+    for (int c = 0; c <= plan.n; c++) a.chunk_begin[c] = plan.begin[c];
+    a.tiles_x = (W + 15) / 16;
+    a.num_slots = (long long)a.tiles_x * ((rows + 15) / 16) * 256;
+    a.num_items = a.num_slots * plan.n;
+}
+
 void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t stream) {
     gd::KernelArgs a{};
     a.spp = rl.spp; a.row_begin = rl.row_begin; a.row_end = rl.row_end; a.max_depth = rl.max_depth;
@@ -58,10 +70,7 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
             launch_eager(sv, a, dim3((unsigned)(a.tiles_x * tiles_y)), stream);
         } else {
             // persistent lanes pulling (pixel, chunk) items: >= 4 samples per item, at most 8 items per pixel
-            a.log2c = render_log2_chunks(rl.spp, rl.force_log2k, (long long)W * rows);
-            a.tiles_x = (W + 15) / 16;
-            const long long tiles = (long long)a.tiles_x * ((rows + 15) / 16);
-            a.num_items = (tiles * 256) << a.log2c;
+            set_chunks(a, rl, W, rows);
             if (a.num_items >= (1LL << 32)) throw std::runtime_error("launch_render: image band too large for the 32-bit work queue");
             a.partials = rl.partials; a.queue_head = rl.queue_head;
             if (!a.partials || !a.queue_head) throw std::runtime_error("launch_render: work-queue buffers missing");
@@ -99,10 +108,7 @@ void launch_path_render(const DevSceneView &sv, const RenderLaunch &rl, hipStrea
         // persistent lanes pulling (pixel, chunk) items, as the GradPath kernel does
         a.thresh_a = rl.thresh_a >= 0 ? (rl.thresh_a > 255 ? 255 : rl.thresh_a) : 64;
         a.thresh_c = rl.thresh_c >= 0 ? (rl.thresh_c > 255 ? 255 : rl.thresh_c) : 112;
-        a.log2c = render_log2_chunks(rl.spp, rl.force_log2k, (long long)W * rows);
-        a.tiles_x = (W + 15) / 16;
-        const long long tiles = (long long)a.tiles_x * ((rows + 15) / 16);
-        a.num_items = (tiles * 256) << a.log2c;
+        set_chunks(a, rl, W, rows);
         if (a.num_items >= (1LL << 32)) throw std::runtime_error("launch_path_render: image band too large for the 32-bit work queue");
         a.partials = rl.partials; a.queue_head = rl.queue_head;
         if (!a.partials || !a.queue_head) throw std::runtime_error("launch_path_render: work-queue buffers missing");
@@ -133,9 +139,6 @@ void launch_path_render(const DevSceneView &sv, const RenderLaunch &rl, hipStrea
     if (e != hipSuccess) throw std::runtime_error(std::string("path kernel launch failed: ") + hipGetErrorString(e));
 }
 
-// Work items per pixel = 2^log2c chunks of its sample range: at least 4 samples per item, at most 8 items per pixel on
-// large films; small bands with many samples (multi-GPU row bands) are cut finer, towards ~2^20 items per launch, so
-// that every lane still sees several items and the drain at the end of the kernel stays one short item long.
 unsigned persistent_blocks(const RenderLaunch &rl, long long num_items) {
     long long waves_needed = (num_items + 63) / 64;
     long long blocks = (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2);
@@ -143,19 +146,47 @@ unsigned persistent_blocks(const RenderLaunch &rl, long long num_items) {
     return (unsigned)(blocks < 1 ? 1 : blocks);
 }
 
-int render_log2_chunks(int spp, int force_log2k, long long pixels) {
-    int by_spp = 0;
-    while ((8 << by_spp) <= spp) by_spp++;                      // 2^by_spp <= spp / 4
-    int target = 0;
-    while (target < 8 && (pixels << target) < (1LL << 20)) target++;
-    int log2c = by_spp < (target > 3 ? target : 3) ? by_spp : (target > 3 ? target : 3);
-    if (force_log2k >= 0) { log2c = force_log2k; while (log2c > 0 && (1 << log2c) > spp) log2c--; }
-    return log2c;
+// Work items per pixel. A lane processes an item's samples one after the other, so when the queue runs dry the kernel
+// still needs as long as its longest unfinished item: with equal chunks of 4+ samples that drain was 0.44 ms of a 2.5 ms
+// launch on cbox 512x512x16 (tests/prof_drain.py; bounding the path length barely changed it, so it is the ITEM, not the
+// longest path). Chunks therefore shrink along the queue — each takes about 40 % of the samples still unassigned, the
+// last ones are single samples — and the queue hands out chunk 0 of every pixel, then chunk 1, ...: long items start
+// early, the tail of the launch consists of one-sample items. 16 spp -> 7,4,2,2,1; 64 -> 26,16,9,6,3,2,1,1; 256 -> 10
+// chunks. Small bands with many samples (multi-GPU row bands) cap the chunk size so that every resident lane still sees
+// several items. One 128-byte partial record per item; gdpt_reduce_partials merges a pixel's records in chunk order,
+// so the result depends neither on which lane ran what nor on when.
+ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long lanes) {
+    ChunkPlan p{};
+    if (spp < 1) spp = 1;
+    if (force_log2k >= 0) {                                    // tests: 2^k equal chunks
+        int k = force_log2k;
+        while (k > 0 && ((1 << k) > spp || (1 << k) > kMaxChunks)) k--;
+        p.n = 1 << k;
+        for (int c = 0; c <= p.n; c++) p.begin[c] = (int)(((long long)c * spp) >> k);
+        return p;
+    }
+    // at least ~4 items per resident lane, as far as the sample count allows
+    long long cap = (long long)spp * pixels / (lanes > 0 ? lanes * 4 : 1);
+    if (cap < 1) cap = 1;
+    if ((long long)spp > cap * (kMaxChunks - 8)) cap = ((long long)spp + kMaxChunks - 9) / (kMaxChunks - 8);   // never more than kMaxChunks chunks
+    int rem = spp, n = 0;
+    p.begin[0] = 0;
+    while (rem > 0) {
+        long long sz = ((long long)rem * 2 + 4) / 5;           // ceil(0.4 * rem)
+        if (sz > cap) sz = cap;
+        if (sz < 1) sz = 1;
+        if (n == kMaxChunks - 1) sz = rem;
+        rem -= (int)sz;
+        p.begin[n + 1] = p.begin[n] + (int)sz;
+        n++;
+    }
+    p.n = n;
+    return p;
 }
 
-size_t render_partials_doubles(int width, int rows, int spp, int force_log2k) {
+size_t render_partials_doubles(int width, int rows, int spp, int force_log2k, long long lanes) {
     const long long tiles = (long long)((width + 15) / 16) * ((rows + 15) / 16);
-    return (size_t)16 * (size_t)((tiles * 256) << render_log2_chunks(spp, force_log2k, (long long)width * rows));
+    return (size_t)16 * (size_t)(tiles * 256) * (size_t)make_chunk_plan(spp, force_log2k, (long long)width * rows, lanes).n;
 }
 
 bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_materials, int bvh_depth) {

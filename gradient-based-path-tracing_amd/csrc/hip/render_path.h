@@ -594,17 +594,16 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_path_persistent(DevSceneView s
 #ifdef GDPT_BUILD_PATH_MISC
 // Sums the per-chunk records of every pixel in chunk order and divides by spp (src/render.cpp:110).
 __global__ __launch_bounds__(256) void gdpt_path_reduce(KernelArgs a, int W) {
-    const long long nslots = a.num_items >> a.log2c;
+    const long long nslots = a.num_slots;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long idx = t >> 2;
     const int j = (int)(t & 3);
     if (idx >= nslots || j == 3) return;
     int x, y, s0, s1;
-    if (!item_to_pixel(a, W, (unsigned)(idx << a.log2c), x, y, s0, s1)) return;
-    const int chunks = 1 << a.log2c;
-    const double *src = a.partials + ((size_t)(idx << a.log2c)) * 4 + j;
+    if (!item_to_pixel(a, W, (unsigned)idx, x, y, s0, s1)) return;
+    const double *src = a.partials + (size_t)idx * 4 + j;
     double v = 0;
-    for (int c = 0; c < chunks; c++) v += src[(size_t)c * 4];
+    for (int c = 0; c < a.num_chunks; c++) v += src[(size_t)c * (size_t)nslots * 4];
     a.img[((size_t)y * W + x) * 3 + j] = v / (double)a.spp;
 }
 

@@ -9,7 +9,7 @@ void launch_path(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, hip
 void launch_path_persistent(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lambert, hipStream_t stream) {
     if (lambert) launch_path_persistent_lambert(sv, a, grid, lds, stream);
     else launch_path_persistent_general(sv, a, grid, lds, stream);
-    const long long nslots = a.num_items >> a.log2c;
+    const long long nslots = a.num_slots;
     hipLaunchKernelGGL(gd::gdpt_path_reduce, dim3((unsigned)((nslots * 4 + 255) / 256)), dim3(256), 0, stream, a, sv.cam.width);
 }
 void launch_tile_path(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream) {

@@ -8,7 +8,7 @@ void launch_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3
     else hipLaunchKernelGGL((gd::gdpt_render_phases<true, false, true, true>), grid, dim3(gd::kBlock), 0, stream, sv, a);
 }
 void launch_reduce_partials(const DevSceneView &sv, const gd::KernelArgs &a, hipStream_t stream) {
-    const long long nslots = a.num_items >> a.log2c;
+    const long long nslots = a.num_slots;
     hipLaunchKernelGGL(gd::gdpt_reduce_partials, dim3((unsigned)((nslots * 16 + 255) / 256)), dim3(256), 0, stream, a, sv.cam.width);
 }
 void launch_tile_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream) {
