@@ -361,9 +361,12 @@ class debug_knobs:
     @staticmethod
     def stamps():
         """Per-segment wave cycles of the last render made under debug_knobs(stamps=1) (include/gdpt_debug.h)."""
-        v = (C.c_double * 12)()
+        v = (C.c_double * 16)()
         lib().gdpt_debug_get_stamps(v)
-        return dict(zip(("loop_head", "trace", "vertex", "consume", "bsdf", "finish", "camera", "wave_steps", "publish", "take", "item"), list(v)))
+        d = dict(zip(("loop_head", "trace", "vertex", "consume", "bsdf", "finish", "camera", "wave_steps", "publish", "take", "item"), list(v)))
+        d["busy_us"] = (v[13] - v[12]) / 100.0      # first wave started -> first wave found the queue empty
+        d["drain_us"] = (v[14] - v[13]) / 100.0     # ... -> last wave ended
+        return d
 
     @staticmethod
     def from_env(environ=None):

@@ -26,11 +26,11 @@ std::mutex g_knob_mu;
 std::map<std::string, double> g_knobs;     // test-only overrides, include/gdpt_debug.h
 const char *const kKnobNames[] = {"force_eager", "log2k", "keep_frac", "search_frac", "blocks_per_cu", "no_lds_scene", "lds_wide",
                                   "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "stamps"};
-double g_stamps[12] = {0};
+double g_stamps[16] = {0};
 } // namespace
 void debug_store_stamps(const unsigned long long *v, int n) {
     std::lock_guard<std::mutex> lk(g_knob_mu);
-    for (int i = 0; i < 12; i++) g_stamps[i] = i < n ? (double)v[i] : 0.0;
+    for (int i = 0; i < 16; i++) g_stamps[i] = i < n ? (double)v[i] : 0.0;
 }
 double debug_knob(const char *name, double def) {
     std::lock_guard<std::mutex> lk(g_knob_mu);
@@ -59,9 +59,9 @@ int gdpt_debug_knob_set(const char *name, double value) {
         gdpt::g_knobs[name] = value;
     });
 }
-void gdpt_debug_get_stamps(double out[12]) {
+void gdpt_debug_get_stamps(double out[16]) {
     std::lock_guard<std::mutex> lk(gdpt::g_knob_mu);
-    for (int i = 0; i < 12; i++) out[i] = gdpt::g_stamps[i];
+    for (int i = 0; i < 16; i++) out[i] = gdpt::g_stamps[i];
 }
 void gdpt_debug_knobs_reset(void) {
     std::lock_guard<std::mutex> lk(gdpt::g_knob_mu);

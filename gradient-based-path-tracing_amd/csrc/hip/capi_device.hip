@@ -451,6 +451,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.lds_wide = rl.scene_fits_lds && env_int("lds_wide", 1) != 0 &&
                   gdpt::scene_fits_lds_wide(sc->view.num_nodes4, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->wide_stack_need);
     ck(hipMemsetAsync(sc->d_counters, 0, sizeof(gdpt::RenderCounters), stream), "hipMemsetAsync(counters)");
+    if (rl.stamped) ck(hipMemsetAsync(&sc->d_counters->stamps[12], 0xFF, 2 * sizeof(unsigned long long), stream), "hipMemsetAsync(stamps)");   // min slots
     if (stats) ck(hipEventRecord(sc->ev0, stream), "hipEventRecord");
     gdpt::launch_render(sc->view, rl, stream);
     if (stats) {
@@ -466,7 +467,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
         stats->render_ms = ms;
         stats->wave_node_trips = sc->h_counters->wave_node_trips; stats->wave_leaf_trips = sc->h_counters->wave_leaf_trips;
         stats->wave_steps = sc->h_counters->wave_steps; stats->lane_steps = sc->h_counters->lane_steps;
-        if (rl.stamped) gdpt::debug_store_stamps(sc->h_counters->stamps, 12);
+        if (rl.stamped) gdpt::debug_store_stamps(sc->h_counters->stamps, 16);
         // only the persistent kernel over an LDS-resident scene can still walk the BVH2 form
         const bool lds_kernel = rl.one_sided_materials && !rl.force_eager && b.rng == GDPT_RNG_SAMPLE && rl.scene_fits_lds;
         stats->node_bytes = (lds_kernel && !rl.lds_wide) ? sizeof(DevBvhNode) : sizeof(DevBvh4Node);

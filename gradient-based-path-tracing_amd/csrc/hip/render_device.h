@@ -46,7 +46,7 @@ struct LaneCounters { unsigned rays, bounces, nonfinite; };
 // wave's cycles go, segment by segment. s_memtime is read by the wave (scalar), so a segment's share includes what the
 // lanes that sit it out wait for — the point of the exercise. The product kernels are built with ON = false: every call
 // below compiles to nothing. Stamp values only ever reach RenderCounters::stamps, never an output image.
-enum { SEG_QUEUE = 0, SEG_TRACE = 1, SEG_VERTEX = 2, SEG_CONSUME = 3, SEG_BSDF = 4, SEG_FINISH = 5, SEG_CAMERA = 6, SEG_STEPS = 7, SEG_PUBLISH = 8, SEG_TAKE = 9, SEG_ITEM = 10, SEG_COUNT = 12 };
+enum { SEG_QUEUE = 0, SEG_TRACE = 1, SEG_VERTEX = 2, SEG_CONSUME = 3, SEG_BSDF = 4, SEG_FINISH = 5, SEG_CAMERA = 6, SEG_STEPS = 7, SEG_PUBLISH = 8, SEG_TAKE = 9, SEG_ITEM = 10, SEG_COUNT = 12, SEG_T_START = 12, SEG_T_DRY = 13, SEG_T_END = 14, SEG_SLOTS = 16 };
 template <bool ON> struct Stamps {
     unsigned long long last, acc[SEG_COUNT];
     GD void start() { if (ON) { for (int i = 0; i < SEG_COUNT; i++) acc[i] = 0; last = __builtin_amdgcn_s_memtime(); } }
@@ -759,6 +759,8 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
     WaveQueue wq;
     Stamps<STAMPED> stamps;
     stamps.start();
+    unsigned long long t_dry = ~0ull;        // diagnostic build: wall clock (100 MHz) when this wave first found the queue empty
+    if (STAMPED && (tid & 63) == 0) atomicMin(&a.counters->stamps[SEG_T_START], __builtin_amdgcn_s_memrealtime());
     for (;;) {
         // ---- hand out work to idle lanes
         const bool idle = (L.st == S_DONE);
@@ -775,6 +777,7 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
         stamps.mark(SEG_PUBLISH);
         const long long got_item = wq.take(a, idle, tid);
         stamps.mark(SEG_TAKE);
+        if (STAMPED && wq.exhausted && t_dry == ~0ull) t_dry = __builtin_amdgcn_s_memrealtime();
         if (got_item >= 0) {
             my_item = got_item;
             int s0, s1;
@@ -795,8 +798,11 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
         }
     }
     flush_counters(a, lc, tc, a.count != 0);
-    if (STAMPED && (tid & 63) == 0)
+    if (STAMPED && (tid & 63) == 0) {
         for (int i = 0; i < SEG_COUNT; i++) atomicAdd(&a.counters->stamps[i], stamps.acc[i]);
+        atomicMin(&a.counters->stamps[SEG_T_DRY], t_dry);
+        atomicMax(&a.counters->stamps[SEG_T_END], __builtin_amdgcn_s_memrealtime());
+    }
 }
 
 #ifdef GDPT_BUILD_REDUCE   // emitted by render_phases_lambert.hip only (non-template kernel)

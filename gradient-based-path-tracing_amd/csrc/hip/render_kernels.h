@@ -12,7 +12,7 @@ struct ChunkPlan { int n; int begin[kMaxChunks + 1]; };
 struct RenderCounters {            // device-resident, zeroed per render
     unsigned long long rays, bounces, nonfinite, nodes, prims;
     unsigned long long wave_node_trips, wave_leaf_trips, wave_steps, lane_steps;   // counting builds: SIMT utilisation
-    unsigned long long stamps[12];  // diagnostic build (knob "stamps"): wave cycles per segment, render_device.h SEG_*
+    unsigned long long stamps[16];  // diagnostic build (knob "stamps"): wave cycles per segment, render_device.h SEG_*
 };
 
 struct RenderLaunch {

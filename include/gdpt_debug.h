@@ -34,8 +34,9 @@ extern "C" {
 int gdpt_debug_knob_set(const char *name, double value);
 /* Wave cycles per segment of the last stamped render (summed over waves): [0] loop head remainder, [1] traversal,
  * [2] hit-vertex rebuild, [3] state arms, [4] BSDF block, [5] offset / finish arm, [6] camera-ray block, [7] wave steps
- * (a count), [8] publishing finished items, [9] work-queue take, [10] item -> pixel mapping, [11] unused. */
-void gdpt_debug_get_stamps(double out[12]);
+ * (a count), [8] publishing finished items, [9] work-queue take, [10] item -> pixel mapping, [11] unused; wall clock
+ * (s_memrealtime, 100 MHz ticks): [12] first wave started, [13] first wave found the queue empty, [14] last wave ended. */
+void gdpt_debug_get_stamps(double out[16]);
 /* Removes every override: the library is back on its product path. */
 void gdpt_debug_knobs_reset(void);
 

@@ -22,9 +22,11 @@ def run(name, xml, film, spp):
     cs = G.GdptRenderStats(); cs.nodes_visited = 2 ** 64 - 1
     p = G._params(spp, G.RNG_SAMPLE, (0, 0))
     G._check(G.lib().gdpt_render(sc.handle, C.byref(p), *[b.ctypes.data_as(C.POINTER(C.c_double)) for b in bufs], C.byref(cs)))
+    busy, drain = stamps.pop("busy_us"), stamps.pop("drain_us")
     tot = sum(v for k, v in stamps.items() if k != "wave_steps")
     print(f"== {name}: render {st.render_ms:.3f} ms ({st.samples / st.render_ms / 1e3:.0f} Msamples/s), stamped build {sst.render_ms:.3f} ms")
     print("   segment shares of wave cycles: " + ", ".join(f"{k} {100 * v / tot:.1f}%" for k, v in stamps.items() if k != "wave_steps"))
+    print(f"   stamped build: queue handed out in {busy:.0f} us, drain of the items in flight {drain:.0f} us")
     ws = stamps["wave_steps"]
     print(f"   wave steps {ws:.0f}; cycles per wave step {tot / ws:.0f}; rays {cs.rays}; rays per wave step {cs.rays / ws:.1f}")
     print(f"   counting build: lane-step utilisation {cs.lane_steps / (64.0 * cs.wave_steps):.3f}; node-loop utilisation {cs.nodes_visited / (64.0 * max(1, cs.wave_node_trips)):.3f}; "
