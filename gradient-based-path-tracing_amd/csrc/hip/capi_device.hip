@@ -35,6 +35,7 @@ T *upload(const std::vector<T> &v) {
 
 } // namespace
 
+static constexpr int kWavefrontDefault = 0;       // HBM scenes: 1 = wavefront pipeline by default, 0 = lane machine
 static constexpr double kPresplitBudget = 0.0;   // extra references / primitives (GDPT_PRESPLIT overrides)
 
 namespace gdpt {
@@ -425,7 +426,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.blocks_per_cu = env_int("blocks_per_cu", 0);
     rl.stamped = env_int("stamps", 0) != 0;
     {
-        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, b.spp, rl.force_log2k, (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256);
+        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, sc->view.cam.height, b.spp, rl.force_log2k, (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256);
         if (need > sc->partials_doubles) {
             if (sc->d_partials) { ck(hipStreamSynchronize(stream), "hipStreamSynchronize"); hipFree(sc->d_partials); sc->d_partials = nullptr; }
             ck(hipMalloc((void **)&sc->d_partials, need * sizeof(double)), "hipMalloc(work-item partials)");
@@ -438,7 +439,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.two_sided_machine = !sc->one_sided && !sc->has_rough && !rl.force_eager && b.rng == GDPT_RNG_SAMPLE && !env_int("no_twosided_machine", 0);
     if (rl.two_sided_machine) {
         const long long tiles = (long long)((sc->view.cam.width + 15) / 16) * ((b.row_end - b.row_begin + 15) / 16);
-        const long long items = (tiles * 256) * gdpt::make_chunk_plan(b.spp, rl.force_log2k, (long long)sc->view.cam.width * (b.row_end - b.row_begin),
+        const long long items = (tiles * 256) * gdpt::make_chunk_plan(b.spp, rl.force_log2k, (long long)sc->view.cam.width * sc->view.cam.height,
                                                                       (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256).n;
         const size_t need = gdpt::twosided_log_bytes(gdpt::persistent_blocks(rl, items));
         if (need > sc->bounce_log_bytes) {
@@ -447,6 +448,32 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
             sc->bounce_log_bytes = need;
         }
         rl.bounce_log = sc->d_bounce_log; rl.bounce_log_bytes = sc->bounce_log_bytes;
+    }
+    // scenes walked from HBM with one-sided lobes: the wavefront pipeline (test knob "wavefront": 0 = lane machine, 1 = wavefront)
+    rl.wavefront = env_int("wavefront", kWavefrontDefault) != 0 && rl.one_sided_materials && !rl.scene_fits_lds && !rl.force_eager &&
+                   b.rng == GDPT_RNG_SAMPLE && b.shift == GDPT_SHIFT_REFERENCE;
+    if (rl.wavefront) {
+        const long long tiles = (long long)((sc->view.cam.width + 15) / 16) * ((b.row_end - b.row_begin + 15) / 16);
+        const long long items = (tiles * 256) * gdpt::make_chunk_plan(b.spp, rl.force_log2k, (long long)sc->view.cam.width * sc->view.cam.height,
+                                                                      (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256).n;
+        int slots = gdpt::wf_slot_count(items);
+        { const int forced = env_int("wf_slots", 0); if (forced > 0) slots = std::min(slots, (forced + 255) / 256 * 256); }   // tests: force slot reuse
+        if (slots > sc->wf_slots) {
+            ck(hipStreamSynchronize(stream), "hipStreamSynchronize");
+            if (sc->d_wf_state) hipFree(sc->d_wf_state);
+            if (sc->d_wf_live) hipFree(sc->d_wf_live);
+            sc->d_wf_state = nullptr; sc->d_wf_live = nullptr; sc->wf_slots = 0;
+            ck(hipMalloc((void **)&sc->d_wf_state, (size_t)slots * gdpt::wf_words() * sizeof(unsigned long long)), "hipMalloc(wavefront state)");
+            ck(hipMalloc((void **)&sc->d_wf_live, (size_t)slots * sizeof(unsigned)), "hipMalloc(wavefront live list)");
+            sc->wf_slots = slots;
+        }
+        if (!sc->d_wf_counters) {
+            ck(hipMalloc((void **)&sc->d_wf_counters, sizeof(unsigned) * 3 * gdpt::wf_max_generations()), "hipMalloc(wavefront counters)");
+            ck(hipHostMalloc((void **)&sc->h_wf_word, sizeof(unsigned)), "hipHostMalloc(wavefront)");
+            ck(hipEventCreateWithFlags(&sc->wf_event, hipEventDisableTiming), "hipEventCreate");
+        }
+        rl.wf_state = sc->d_wf_state; rl.wf_live = sc->d_wf_live; rl.wf_counters = sc->d_wf_counters; rl.wf_host = sc->h_wf_word;
+        rl.wf_event = sc->wf_event; rl.wf_slots = slots;       // exactly the slots this band needs (the buffers may be larger)
     }
     rl.lds_wide = rl.scene_fits_lds && env_int("lds_wide", 1) != 0 &&
                   gdpt::scene_fits_lds_wide(sc->view.num_nodes4, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->wide_stack_need);
@@ -500,7 +527,7 @@ void path_render_device_impl(GdptScene *sc, const GdptRenderParams *params, doub
     rl.scene_fits_lds = !env_int("no_lds_scene", 0) &&
                         gdpt::scene_fits_lds_wide(sc->view.num_nodes4, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->wide_stack_need);
     {
-        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, b.spp, rl.force_log2k, (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256);
+        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, sc->view.cam.height, b.spp, rl.force_log2k, (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256);
         if (need > sc->partials_doubles) {
             if (sc->d_partials) { ck(hipStreamSynchronize(stream), "hipStreamSynchronize"); hipFree(sc->d_partials); sc->d_partials = nullptr; }
             ck(hipMalloc((void **)&sc->d_partials, need * sizeof(double)), "hipMalloc(work-item partials)");

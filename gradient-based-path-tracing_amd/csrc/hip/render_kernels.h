@@ -37,6 +37,14 @@ struct RenderLaunch {
     size_t bounce_log_bytes;
     int num_cus;                   // compute units of the device (persistent grid size)
     int blocks_per_cu;             // persistent blocks per CU (0 = default 2)
+    // wavefront pipeline (render_wavefront.h): scenes walked from HBM, one-sided lobes, SAMPLE streams
+    bool wavefront;
+    unsigned long long *wf_state;  // device, wf_words() * wf_slots 8-byte words
+    unsigned *wf_live;             // device, wf_slots
+    unsigned *wf_counters;         // device, 3 * wf_max_generations()
+    unsigned *wf_host;             // pinned, 1 word (live-count read-back)
+    hipEvent_t wf_event;
+    int wf_slots;
     bool stamped;                  // diagnostic build with in-kernel cycle stamps (test-only knob "stamps")
     double *partials;              // device, >= 15 * W * rows * 8 doubles (work-item partial sums)
     unsigned long long *queue_head;// device, work-queue head
@@ -51,8 +59,12 @@ void launch_path_render(const DevSceneView &sv, const RenderLaunch &rl, hipStrea
 // Chunk sizes shrink along the queue (about 40 % of what is left each time, ending in single samples) unless
 // force_log2k >= 0 asks for 2^k equal chunks (tests). `lanes` = resident lanes of the persistent grid.
 ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long lanes);
-size_t render_partials_doubles(int width, int rows, int spp, int force_log2k, long long lanes);
+size_t render_partials_doubles(int width, int rows, int film_height, int spp, int force_log2k, long long lanes);
 
+int wf_words();
+int wf_max_generations();
+// Path slots of the wavefront pipeline for a band of `num_items` work items.
+int wf_slot_count(long long num_items);
 // Enqueues the five-buffer render on `stream`. Throws std::runtime_error on a launch failure.
 void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t stream);
 // Name of the dominant kernel of the last launch configuration (for rocprof matching).

@@ -1,5 +1,5 @@
 // render_kernels.hip — launch dispatch of the GDPT render kernels (device code: render_device.h).
-#include "render_device.h"
+#include "render_wavefront.h"
 
 #include <stdexcept>
 #include <string>
@@ -13,13 +13,56 @@ const char *render_kernel_name(int rng_scheme) {
 static long long resident_lanes(const RenderLaunch &rl) { return (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * gd::kBlock; }
 
 // item layout of the persistent kernels (render_device.h: item_to_pixel)
-static void set_chunks(gd::KernelArgs &a, const RenderLaunch &rl, int W, int rows) {
-    const ChunkPlan plan = make_chunk_plan(rl.spp, rl.force_log2k, (long long)W * rows, resident_lanes(rl));
+// The plan is made for the WHOLE film, whatever band is rendered: a pixel's samples are cut (and its partial sums
+// merged) the same way on one device and on eight, so sharded renders equal the unsharded one bit for bit.
+static void set_chunks(gd::KernelArgs &a, const RenderLaunch &rl, int W, int rows, int film_h) {
+    const ChunkPlan plan = make_chunk_plan(rl.spp, rl.force_log2k, (long long)W * film_h, resident_lanes(rl));
     a.num_chunks = plan.n;
     for (int c = 0; c <= plan.n; c++) a.chunk_begin[c] = plan.begin[c];
     a.tiles_x = (W + 15) / 16;
     a.num_slots = (long long)a.tiles_x * ((rows + 15) / 16) * 256;
     a.num_items = a.num_slots * plan.n;
+}
+
+int wf_words() { return gd::WF_WORDS; }
+int wf_max_generations() { return gd::kWfMaxGen; }
+int wf_slot_count(long long num_items) {
+    long long n = num_items < (1LL << 21) ? num_items : (1LL << 21);       // 2 M slots = 0.8 GB of path state
+    n = (n + gd::kBlock - 1) / gd::kBlock * gd::kBlock;
+    return (int)(n < gd::kBlock ? gd::kBlock : n);
+}
+
+// Generations are enqueued in chunks; the host reads the number of slots that still need a step one chunk behind the
+// launches (the speculative chunk behind a finished render finds nothing to do: its kernels return at once).
+static void run_wavefront(const DevSceneView &sv, const gd::KernelArgs &a, const RenderLaunch &rl, hipStream_t stream) {
+    if (!rl.wf_state || !rl.wf_live || !rl.wf_counters || !rl.wf_host || rl.wf_slots <= 0) throw std::runtime_error("launch_render: wavefront buffers missing");
+    gd::WfBuf w{};
+    w.state = rl.wf_state; w.live = rl.wf_live; w.counters = rl.wf_counters; w.n = rl.wf_slots; w.gen = 0;
+    auto ckh = [](hipError_t e, const char *what) { if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e)); };
+    ckh(hipMemsetAsync(rl.wf_counters, 0, sizeof(unsigned) * 3 * gd::kWfMaxGen, stream), "hipMemsetAsync(wavefront counters)");
+    launch_wf_init(w, stream);
+    // trace kernel: persistent, kWfTraceWaves waves per SIMD
+    const unsigned trace_blocks = (unsigned)rl.num_cus * (unsigned)gd::kWfTraceWaves;
+    const int chunk = 8;
+    int gen = 0;
+    auto enqueue_chunk = [&]() {
+        for (int k = 0; k < chunk; k++, gen++) {
+            if (gen >= gd::kWfMaxGen) throw std::runtime_error("launch_render: wavefront generation limit reached");
+            w.gen = gen;
+            if (rl.lambert_only) launch_wf_step_lambert(sv, a, w, stream); else launch_wf_step_general(sv, a, w, stream);
+            launch_wf_trace(sv, a, w, trace_blocks, stream);
+        }
+    };
+    enqueue_chunk();
+    for (;;) {
+        ckh(hipMemcpyAsync(rl.wf_host, rl.wf_counters + 2 * gd::kWfMaxGen + (gen - 1), sizeof(unsigned), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(wavefront live count)");
+        ckh(hipEventRecord(rl.wf_event, stream), "hipEventRecord");
+        const bool room = gen + chunk <= gd::kWfMaxGen;
+        if (room) enqueue_chunk();
+        ckh(hipEventSynchronize(rl.wf_event), "hipEventSynchronize");
+        if (*rl.wf_host == 0u) break;
+        if (!room) throw std::runtime_error("launch_render: wavefront generation limit reached");
+    }
 }
 
 void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t stream) {
@@ -70,7 +113,7 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
             launch_eager(sv, a, dim3((unsigned)(a.tiles_x * tiles_y)), stream);
         } else {
             // persistent lanes pulling (pixel, chunk) items: >= 4 samples per item, at most 8 items per pixel
-            set_chunks(a, rl, W, rows);
+            set_chunks(a, rl, W, rows, sv.cam.height);
             if (a.num_items >= (1LL << 32)) throw std::runtime_error("launch_render: image band too large for the 32-bit work queue");
             a.partials = rl.partials; a.queue_head = rl.queue_head;
             if (!a.partials || !a.queue_head) throw std::runtime_error("launch_render: work-queue buffers missing");
@@ -78,7 +121,9 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
             if (me != hipSuccess) throw std::runtime_error("launch_render: queue reset failed");
             const unsigned blocks = persistent_blocks(rl, a.num_items);   // 2 resident blocks per CU (LDS-bound)
             dim3 grid(blocks);
-            if (rl.two_sided_machine) {
+            if (rl.wavefront && !rl.two_sided_machine && !rl.scene_fits_lds) {
+                run_wavefront(sv, a, rl, stream);
+            } else if (rl.two_sided_machine) {
                 if (!rl.bounce_log || rl.bounce_log_bytes < twosided_log_bytes(blocks)) throw std::runtime_error("launch_render: bounce log missing");
                 launch_phases_twosided(sv, a, grid, rl.scene_fits_lds && rl.lds_wide, rl.bounce_log, stream);
             } else if (rl.lambert_only && rl.stamped && (!rl.scene_fits_lds || rl.lds_wide)) launch_phases_lambert_stamped(sv, a, grid, rl.scene_fits_lds, stream);
@@ -108,7 +153,7 @@ void launch_path_render(const DevSceneView &sv, const RenderLaunch &rl, hipStrea
         // persistent lanes pulling (pixel, chunk) items, as the GradPath kernel does
         a.thresh_a = rl.thresh_a >= 0 ? (rl.thresh_a > 255 ? 255 : rl.thresh_a) : 64;
         a.thresh_c = rl.thresh_c >= 0 ? (rl.thresh_c > 255 ? 255 : rl.thresh_c) : 112;
-        set_chunks(a, rl, W, rows);
+        set_chunks(a, rl, W, rows, sv.cam.height);
         if (a.num_items >= (1LL << 32)) throw std::runtime_error("launch_path_render: image band too large for the 32-bit work queue");
         a.partials = rl.partials; a.queue_head = rl.queue_head;
         if (!a.partials || !a.queue_head) throw std::runtime_error("launch_path_render: work-queue buffers missing");
@@ -184,9 +229,9 @@ ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long 
     return p;
 }
 
-size_t render_partials_doubles(int width, int rows, int spp, int force_log2k, long long lanes) {
+size_t render_partials_doubles(int width, int rows, int film_height, int spp, int force_log2k, long long lanes) {
     const long long tiles = (long long)((width + 15) / 16) * ((rows + 15) / 16);
-    return (size_t)16 * (size_t)(tiles * 256) * (size_t)make_chunk_plan(spp, force_log2k, (long long)width * rows, lanes).n;
+    return (size_t)16 * (size_t)(tiles * 256) * (size_t)make_chunk_plan(spp, force_log2k, (long long)width * film_height, lanes).n;
 }
 
 bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_materials, int bvh_depth) {

@@ -35,6 +35,10 @@ struct GdptScene {
     void *d_bounce_log = nullptr; size_t bounce_log_bytes = 0;   // per-lane bounce log of the two-sided lane machine
     double *d_partials = nullptr; size_t partials_doubles = 0;   // work-item partial sums of the persistent render kernel
     unsigned long long *d_queue = nullptr;
+    // wavefront pipeline (render_wavefront.h): path state, live list, generation counters
+    unsigned long long *d_wf_state = nullptr; unsigned *d_wf_live = nullptr, *d_wf_counters = nullptr, *h_wf_word = nullptr;
+    int wf_slots = 0;
+    hipEvent_t wf_event = nullptr;
     int num_cus = 256;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -55,6 +59,11 @@ struct GdptScene {
         if (d_partials) hipFree(d_partials);
         if (d_bounce_log) hipFree(d_bounce_log);
         if (d_queue) hipFree(d_queue);
+        if (d_wf_state) hipFree(d_wf_state);
+        if (d_wf_live) hipFree(d_wf_live);
+        if (d_wf_counters) hipFree(d_wf_counters);
+        if (h_wf_word) hipHostFree(h_wf_word);
+        if (wf_event) hipEventDestroy(wf_event);
         if (h_counters) hipHostFree(h_counters);
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);

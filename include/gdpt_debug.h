@@ -21,6 +21,9 @@
  *   presplit_floor       (real) pre-split priority floor (scene upload)
  *   bvh_leaf_max         (1..4) SAH builder: primitives per leaf (scene upload)
  *   bvh_leaf_factor      (real) SAH builder: leaf cost factor (scene upload)
+ *   wavefront            (0/1)  scenes walked from HBM, one-sided lobes: 1 = wavefront pipeline (step + trace kernels, path
+ *                               state in HBM), 0 = lane machine; the two give bit-identical images
+ *   wf_slots             (int)  wavefront pipeline: at most this many path slots (forces slots to run several items)
  *   stamps               (0/1)  Lambertian lane machine: the diagnostic build with in-kernel cycle stamps; a render with
  *                               stats then leaves its per-segment wave cycles for gdpt_debug_get_stamps
  */

@@ -53,26 +53,37 @@ def test_baseline_config_at_its_own_size(G, O, scene_tmp, name, rel, film, integ
     out, bufs, rs, ps = sc.gradient_path_render(spp, G.RNG_SAMPLE, return_buffers=True)
     # accounting
     assert rs.samples == W * H * spp
-    assert rs.nonfinite_samples == 0 and np.isfinite(out).all()
-    for k in BUFS:
-        assert np.isfinite(bufs[k]).all(), k
     assert rs.rays >= rs.samples                                   # at least the base primary ray
     assert bounce_range[0] < rs.bounces / rs.samples < bounce_range[1], rs.bounces / rs.samples
     # determinism: the same launch again, bit for bit (one writer per partial-sum slot, ordered merge)
     out2 = sc.gradient_path_render(spp, G.RNG_SAMPLE)
-    assert np.array_equal(out, out2)
-    # reconstruction: GPU solve == DCT oracle on the GPU's own buffers; DC override invariant
-    c, cx, cy = O.assemble(bufs)
-    ref = O.fourier_solve(c, cx, cy, 0.04)
-    assert rel_l2(out, ref) < 1e-10
-    wgt = weights(W, H)
-    # (absolute slack scaled by the magnitude summed: the Disney primal is exactly zero while the gradients are not)
-    np.testing.assert_allclose((wgt * out).sum(axis=(0, 1)), (wgt * c).sum(axis=(0, 1)), rtol=1e-10, atol=1e-11 * float(np.abs(wgt * out).sum()))
-    # a 16-row band (one tile row, mid image) against the oracle
-    r0 = (H // 2) // 16 * 16
+    assert np.array_equal(out, out2, equal_nan=True)
+    bad_rows = sorted({int(r) for k in BUFS for r in np.argwhere(~np.isfinite(bufs[k]).all(axis=(1, 2)))[:, 0]})
+    if rs.nonfinite_samples == 0:
+        assert not bad_rows and np.isfinite(out).all()
+        # reconstruction: GPU solve == DCT oracle on the GPU's own buffers; DC override invariant
+        c, cx, cy = O.assemble(bufs)
+        ref = O.fourier_solve(c, cx, cy, 0.04)
+        assert rel_l2(out, ref) < 1e-10
+        wgt = weights(W, H)
+        # (absolute slack scaled by the magnitude summed: the Disney primal is exactly zero while the gradients are not)
+        np.testing.assert_allclose((wgt * out).sum(axis=(0, 1)), (wgt * c).sum(axis=(0, 1)), rtol=1e-10, atol=1e-11 * float(np.abs(wgt * out).sum()))
+        r0 = (H // 2) // 16 * 16
+    else:
+        # The reference has no isfinite guard in gradient_path_render (contrast src/render.cpp:156): a non-finite sample goes
+        # into its pixel and, through the global DCT, into the whole output (SURVEY.md 8(c) finding v). Parity = the same
+        # thing happens here: only the two-sided Disney lobes produce such samples, the counter reports them, the pixels they
+        # land in are the ones the oracle gets, and the reconstruction is non-finite everywhere.
+        assert "disney_glass" in rel or "disney_bsdf" in rel, "non-finite samples outside the two-sided Disney lobes"
+        assert 0 < len(bad_rows) <= rs.nonfinite_samples and not np.isfinite(out).any()
+        r0 = bad_rows[0] // 16 * 16
+    # a 16-row band (one tile row: mid image, or the one holding the first non-finite pixel) against the oracle
     ob, ost = O.OracleScene(sd.ptr, use_bvh=True).render(spp, G.RNG_SAMPLE, rows=(r0, r0 + 16), threads=os.cpu_count())
     for k in BUFS:
-        err = rel_l2(bufs[k][r0:r0 + 16], ob[k][r0:r0 + 16])
+        got, want = bufs[k][r0:r0 + 16], ob[k][r0:r0 + 16]
+        assert np.array_equal(np.isfinite(got), np.isfinite(want)), f"{name} {k}: non-finite pixels differ from the oracle's"
+        m = np.isfinite(want)
+        err = rel_l2(got[m], want[m])
         assert err < tol, f"{name} {k}: rel L2 {err}"
     if "disney" in rel:
         # lit by an environment map only, which GradPath ignores (src/path_tracing.h:982-985): the primal is exactly zero

@@ -279,3 +279,36 @@ def test_closest_hit_does_not_depend_on_the_tree(G, scene_tmp, rel, integ, monke
     for k in BUFS:
         assert np.array_equal(np.asarray(a[k]), np.asarray(b[k]), equal_nan=True), k
     assert sa.rays == sb.rays and sa.bounces == sb.bounces
+
+
+@pytest.mark.parametrize("rel, integ, film, spp", [("sponza/sponza.xml", None, (200, 112), 6), ("disney_bsdf_test/disney_metal.xml", "gradpath", (96, 80), 5),
+                                                   ("sponza/sponza.xml", None, (33, 17), 3), ("sponza/sponza.xml", None, (640, 360), 24)])
+def test_wavefront_pipeline_equals_the_lane_machine(G, O, scene_tmp, rel, integ, film, spp):
+    """Scenes walked from HBM can run as a wavefront pipeline (render_wavefront.h: a step kernel over path slots whose state
+    lives in HBM + a persistent trace kernel, one generation per ray) instead of the lane machine. Same per-sample program,
+    same streams, same per-item summation order: the five buffers must be bit-identical, counters included, and equal
+    the oracle."""
+    xml = scene_variant(scene_tmp, rel, width=film[0], height=film[1], integrator=integ)
+    sd = G.parse_scene(xml)
+    sc = G.Scene(sd)
+    with G.debug_knobs(wavefront=0):
+        lane, ls = sc.render(spp, G.RNG_SAMPLE)
+    with G.debug_knobs(wavefront=1):
+        wave, ws = sc.render(spp, G.RNG_SAMPLE)
+        band, bs = sc.render(spp, G.RNG_SAMPLE, rows=(16, 48) if film[1] >= 48 else (0, 16))
+    with G.debug_knobs(wavefront=1, wf_slots=max(512, film[0] * film[1] // 4)):        # far fewer slots than work items: every slot runs many items in turn
+        few, fs = sc.render(spp, G.RNG_SAMPLE)
+    for k in BUFS:
+        assert np.array_equal(lane[k], few[k]), k
+    assert (fs.rays, fs.bounces) == (ls.rays, ls.bounces)
+    for k in BUFS:
+        assert np.array_equal(lane[k], wave[k]), k
+    assert (ls.rays, ls.bounces, ls.samples, ls.nonfinite_samples) == (ws.rays, ws.bounces, ws.samples, ws.nonfinite_samples)
+    r0, r1 = (16, 48) if film[1] >= 48 else (0, 16)
+    for k in BUFS:
+        assert np.array_equal(band[k][r0:r1], lane[k][r0:r1]), k          # a row band through the same pipeline
+    if film[0] * film[1] * spp > 400000:      # (640x360x24: items of up to 10 samples — the accumulation across an item's samples
+        return                                # must round alike in both pipelines; too large for the oracle in a test)
+    want, ost = O.OracleScene(sd.ptr, use_bvh=True).render(spp, G.RNG_SAMPLE, threads=8)
+    check_buffers(wave, want, 1e-7)
+    assert ws.bounces == ost.bounces
