@@ -27,13 +27,20 @@ namespace gd {
 struct ShiftV1 { Vertex v; D3 dir_view; bool ok; };
 
 // Lambert-only scenes inline the three-line lobe; everything else goes through the full material switch.
-// (Out-of-line copies of the switch — __noinline__ — faulted on the device at full size and were dropped; the general
-// kernel is instantiated for HBM scenes only to keep its compile time in bounds.)
+// GDPT_RECONNECT_OUTLINE (diagnostic build only, `make outline-diag` + tests/diag_reconnect_outline.py) makes the switch
+// two out-of-line functions instead: 264 instead of 1103 spilled VGPRs, but 3152 instead of 1728 bytes of scratch per
+// lane (the caller parks everything live across the calls) and arguments handed over as generic pointers into the
+// caller's scratch; DESIGN.md 4.4 records what that build does on the device.
+#ifdef GDPT_RECONNECT_OUTLINE
+#define GDPT_MAT_CALL __device__ __noinline__
+#else
+#define GDPT_MAT_CALL GD
+#endif
 template <bool LAMBERT> struct Mat {
-    static GD bool sample(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D2 ruv, double rw, BsdfSample &s) {
+    static GDPT_MAT_CALL bool sample(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D2 ruv, double rw, BsdfSample &s) {
         return mat_sample<LAMBERT, true, true>(sv, tx, v, in, ruv, rw, s);
     }
-    static GD void eval_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D3 out, D3 &f, double &pdf) {
+    static GDPT_MAT_CALL void eval_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D3 out, D3 &f, double &pdf) {
         mat_eval_pdf<LAMBERT, true, true>(sv, tx, v, in, out, f, pdf);
     }
 };
