@@ -288,6 +288,40 @@ def run_rank(args):
     G._check(G.lib().gdpt_render_device(scene.handle, C.byref(p), *[C.c_void_p(ptr(pipe.bufs[k])) for k in names],
                                         C.c_void_p(stream), C.byref(cs)))
 
+    # ---- supplementary: two frames in flight (N = 1 only). A launch ends with the drain of its longest paths (0.4 ms of
+    # 2.4 on this workload: DESIGN.md 4.1) during which most of the chip idles; a renderer that produces a stream of
+    # frames starts the next frame's render on a second stream meanwhile. Same work per step, same kernels, every step still
+    # render -> assemble -> solve; `value` above stays the one-frame-at-a-time figure.
+    pipelined = None
+    if world == 1 and args.shift == "reference" and not args.no_strong:
+        scene2 = G.Scene(sd, device=local_rank)                  # a scene handle owns one set of launch scratch: one per frame in flight
+        side = torch.cuda.Stream(device=dev)
+
+        def make2(sc, st_):
+            def render_band(bufs, rows, want_stats):
+                return sc.render_device([ptr(bufs[k]) for k in names], spp=spp_total, rng_scheme=G.RNG_SAMPLE, rows=rows, stream=st_, want_stats=False, shift=shift)
+
+            def assemble(bufs, dst, rows):
+                G.assemble_device(W, H, [ptr(bufs[k]) for k in names], [ptr(t) for t in dst], stream=st_, rows=rows)
+
+            def solve(c, cx, cy, out, want_stats):
+                return G.poisson_solve_device(W, H, ptr(c), ptr(cx), ptr(cy), ptr(out), alpha=args.alpha, stream=st_, want_stats=False)
+            return sharding.ShardedGradPath(None, 1, 0, H, lambda: torch.zeros((H, W, 3), dtype=torch.float64, device=dev), render_band, assemble, solve)
+        pa, pb = make2(scene, stream), make2(scene2, side.cuda_stream)
+        for _ in range(2):
+            pa.step(); pb.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            (pa if k % 2 == 0 else pb).step()
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t0
+        same = bool(torch.equal(pa.out, pipe.out) and torch.equal(pb.out, pipe.out))
+        pipelined = {"frames_in_flight": 2, "steps": args.steps, "ms_per_step": el2 / args.steps * 1e3,
+                     "value": samples_all / (el2 / args.steps) / 1e6, "unit": "Msamples/s", "outputs_equal_sequential": same,
+                     "note": "consecutive frames alternate between two HIP streams and two scene handles; not the headline value"}
+        del pa, pb, scene2
+
     # ---- strong scaling: the north-star target, 256 spp in total split over the bands
     strong = None
     if not args.no_strong and args.shift == "reference":
@@ -327,6 +361,7 @@ def run_rank(args):
         "rays_per_sample": cs.rays / max(1, cs.samples), "bounces_per_sample": cs.bounces / max(1, cs.samples),
         "nonfinite_samples": int(rs.nonfinite_samples) if rs is not None else None,
         "scaling_strong": strong,
+        "pipelined": pipelined,
     }
     if rehearsal:
         result["rehearsal"] = (f"{world} ranks on {ndev} visible GPU(s), exchange staged through host memory over gloo: exercises the "
@@ -406,7 +441,7 @@ def _num_chunks(spp, pixels, lanes=256 * 2 * 256):
     cap = max(1, spp * pixels // (lanes * 4))
     rem, n = spp, 0
     while rem > 0:
-        sz = min(max(1, (rem * 2 + 4) // 5), cap)
+        sz = 1 if rem <= 2 else min(max(1, (rem * 11 + 19) // 20), cap)
         if n == 63:
             sz = rem
         rem -= sz

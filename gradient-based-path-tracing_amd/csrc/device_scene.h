@@ -87,8 +87,10 @@ struct DevCamera {
     double cam_to_world[16];
     double org[3];       // xform_point(cam_to_world, 0) — constant per render (src/camera.cpp:42)
     int32_t width, height;
-    int32_t filter_type, pad;
+    int32_t filter_type;
+    int32_t pow2_film;   // width and height are powers of two: x / width is an exact scaling (camera fast path)
     double filter_param;
+    double inv_width, inv_height;   // 1 / width, 1 / height (exact when pow2_film)
 };
 
 // Everything a kernel needs, passed by value as one kernel argument (pointers are device pointers).

@@ -266,6 +266,8 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
         v.cam.org[0] = m[3] * inv_w; v.cam.org[1] = m[7] * inv_w; v.cam.org[2] = m[11] * inv_w;
     }
     v.cam.width = cam.width; v.cam.height = cam.height; v.cam.filter_type = cam.filter_type; v.cam.filter_param = cam.filter_param;
+    v.cam.pow2_film = ((cam.width & (cam.width - 1)) == 0 && (cam.height & (cam.height - 1)) == 0) ? 1 : 0;
+    v.cam.inv_width = 1.0 / (double)cam.width; v.cam.inv_height = 1.0 / (double)cam.height;
     v.nodes = sc->keep(upload(bvh.nodes));
     v.nodes4 = sc->keep(upload(nodes4));
     v.prims = sc->keep(upload(prims));

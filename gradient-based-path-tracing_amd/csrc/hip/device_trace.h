@@ -252,8 +252,14 @@ GD D3 xform_vector(const double *m, D3 v) {
 // `cache` (optional): the sub-pixel numbers (dx,dy) and filter offset of the lane's base ray. An offset ray whose
 // (dx,dy) are bit-identical (always, for power-of-two film sizes) reuses the offset instead of re-evaluating the filter.
 struct FilterCache { double dx, dy, ox, oy; };
+// PIXEL_SPACE: (sx, sy) are the pixel-space numbers (x + u, y + v) the caller would otherwise divide by the film extent.
+// For power-of-two films that division, the multiplication back (src/camera.cpp:26-27) and the division of the filtered
+// position are exact scalings by 2^-k: the fast path skips them and gets the reference's bits with four fp64 divisions less.
+template <bool PIXEL_SPACE = false>
 GD Ray sample_primary(const DevCamera &cam, double sx, double sy, FilterCache *cache = nullptr, bool store = false) {
-    double ppx = sx * cam.width, ppy = sy * cam.height;
+    const bool exact = PIXEL_SPACE && cam.pow2_film != 0;        // wave-uniform
+    if (PIXEL_SPACE && !exact) { sx = sx / cam.width; sy = sy / cam.height; }
+    double ppx = exact ? sx : sx * cam.width, ppy = exact ? sy : sy * cam.height;
     double fx = floor(ppx), fy = floor(ppy);
     D2 off;
     if (cache && !store && cache->dx == ppx - fx && cache->dy == ppy - fy) { off.x = cache->ox; off.y = cache->oy; }
@@ -261,7 +267,9 @@ GD Ray sample_primary(const DevCamera &cam, double sx, double sy, FilterCache *c
         off = filter_sample(cam.filter_type, cam.filter_param, ppx - fx, ppy - fy);
         if (cache && store) { cache->dx = ppx - fx; cache->dy = ppy - fy; cache->ox = off.x; cache->oy = off.y; }
     }
-    double rx = (fx + 0.5 + off.x) / cam.width, ry = (fy + 0.5 + off.y) / cam.height;
+    double rx, ry;
+    if (exact) { rx = (fx + 0.5 + off.x) * cam.inv_width; ry = (fy + 0.5 + off.y) * cam.inv_height; }
+    else { rx = (fx + 0.5 + off.x) / cam.width; ry = (fy + 0.5 + off.y) / cam.height; }
     D3 pt = xform_point(cam.sample_to_cam, mk(rx, ry, 0.0));
     D3 dir = normalize(pt);
     Ray r;

@@ -570,7 +570,7 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
         }
         FilterCache fc;
         if (act == ACT_OFFSET_RAY) fc = lp.fc();
-        Ray r = sample_primary(cam, ((x + ox) + rx) / w, ((y + oy) + ry) / h, &fc, act == ACT_PRIMARY_RAY);
+        Ray r = sample_primary<true>(cam, (x + ox) + rx, (y + oy) + ry, &fc, act == ACT_PRIMARY_RAY);
         if (act == ACT_PRIMARY_RAY) lp.set_fc(fc);
         L.org = r.org; L.dir = r.dir;
     }

@@ -194,10 +194,10 @@ unsigned persistent_blocks(const RenderLaunch &rl, long long num_items) {
 // Work items per pixel. A lane processes an item's samples one after the other, so when the queue runs dry the kernel
 // still needs as long as its longest unfinished item: with equal chunks of 4+ samples that drain was 0.44 ms of a 2.5 ms
 // launch on cbox 512x512x16 (tests/prof_drain.py; bounding the path length barely changed it, so it is the ITEM, not the
-// longest path). Chunks therefore shrink along the queue — each takes about 40 % of the samples still unassigned, the
+// longest path). Chunks therefore shrink along the queue — each takes about 55 % of the samples still unassigned, the
 // last ones are single samples — and the queue hands out chunk 0 of every pixel, then chunk 1, ...: long items start
-// early, the tail of the launch consists of one-sample items. 16 spp -> 7,4,2,2,1; 64 -> 26,16,9,6,3,2,1,1; 256 -> 10
-// chunks. Small bands with many samples (multi-GPU row bands) cap the chunk size so that every resident lane still sees
+// early, the tail of the launch consists of one-sample items. 16 spp -> 9,4,2,1 (as many partial records as the four
+// equal chunks before); 64 -> 36,16,7,3,1,1; 256 -> 141,64,29,13,5,2,1,1. Small bands with many samples (multi-GPU row bands) cap the chunk size so that every resident lane still sees
 // several items. One 128-byte partial record per item; gdpt_reduce_partials merges a pixel's records in chunk order,
 // so the result depends neither on which lane ran what nor on when.
 ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long lanes) {
@@ -217,7 +217,8 @@ ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long 
     int rem = spp, n = 0;
     p.begin[0] = 0;
     while (rem > 0) {
-        long long sz = ((long long)rem * 2 + 4) / 5;           // ceil(0.4 * rem)
+        long long sz = ((long long)rem * 11 + 19) / 20;        // ceil(0.55 * rem)
+        if (rem <= 2) sz = 1;                                  // the tail of the queue: single samples
         if (sz > cap) sz = cap;
         if (sz < 1) sz = 1;
         if (n == kMaxChunks - 1) sz = rem;

@@ -186,7 +186,7 @@ GD void lane_step2(const DevSceneView &sv, const TraceCtx &tx, int max_depth, do
         }
         FilterCache fc;
         if (act == ACT_OFFSET_RAY) fc = lp.fc();
-        Ray pr = sample_primary(cam, ((x + ox) + rx) / w, ((y + oy) + ry) / h, &fc, act == ACT_PRIMARY_RAY);
+        Ray pr = sample_primary<true>(cam, (x + ox) + rx, (y + oy) + ry, &fc, act == ACT_PRIMARY_RAY);
         if (act == ACT_PRIMARY_RAY) lp.set_fc(fc);
         L.org = pr.org; L.dir = pr.dir;
     }

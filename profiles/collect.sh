@@ -8,7 +8,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="$ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="$ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-pmc --no-strong"
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o run --output-format csv -- python3 $BENCH > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o run --output-format csv -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_write -o run --output-format csv -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_write.err
