@@ -11,7 +11,7 @@ FILTER_BOX, FILTER_TENT, FILTER_GAUSSIAN = 0, 1, 2
 INTEGRATOR_PATH, INTEGRATOR_GRADPATH, INTEGRATOR_OTHER = 5, 7, -1
 RNG_TILE, RNG_SAMPLE = 0, 2
 SHIFT_REFERENCE, SHIFT_RECONNECT = 0, 1
-SOLVER_CG, SOLVER_DCT = 0, 1
+SOLVER_CG, SOLVER_DCT, SOLVER_DCT_MFMA = 0, 1, 2
 
 
 class GdptTexture(C.Structure):

@@ -262,6 +262,122 @@ __global__ __launch_bounds__(kBlock) void dct_finalize_kernel(Geo g, const doubl
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The 1-D transforms as hand-written fp64 MFMA GEMMs (v_mfma_f64_16x16x4_f64), epilogues fused.
+//   C[M x N] = A[M x K] * B[K x N], row-major, one matrix per channel (blockIdx.z; the transform matrix has stride 0).
+// Block = 4 waves, block tile 64 x 64, K step 16 staged through LDS, double-buffered: while the MFMAs of step s run, the
+// global loads of step s+1 are in flight and land in the other LDS buffer. Both operands sit k-major in LDS
+// ([k][m] and [k][n], row stride 80 doubles = 160 dwords, so the four k rows a wave reads at once fall on different bank
+// halves: conflict-free ds_read_b64); a wave owns a 32 x 32 quadrant = 2 x 2 MFMA tiles. Operand lanes: A[row l&15][k l>>4],
+// B[k l>>4][col l&15]; result register r of lane l is C[(l>>4) + 4r][l&15] (the f64 map, not the f32 one).
+// Epilogues (EPI): 0 plain; 1 the spectral division  F^ = H^ / (alpha - (float)(lapY[y] + lapX[x]))  with the DC override
+// F^[0,0] = sum(w u) (src/render.cpp:229-239: the block holding element (0,0) reduces the per-block partials of
+// dct_rhs_kernel itself); 2 the final  out[(y*W+x)*3+ch] = f / (4 (W-1)(H-1))  (:245-247), planar -> interleaved.
+constexpr int kGemmBM = 64, kGemmBN = 64, kGemmBK = 16, kGemmLdB = 80, kGemmLdA = 18;
+struct GemmEpi {
+    double alpha; const double *lap_x, *lap_y;      // EPI 1
+    const double *dc_partials; int dc_nb;            // EPI 1: [3][dc_nb] block partials of sum(w u)
+    double denom; double *out; int out_w;            // EPI 2
+};
+// Block tile 64 x 64, K step 16, double-buffered, two blocks per CU. LDS images: A tile row-major [64][18] (the MFMA's A
+// lanes read [row l&15][k l>>4]: 36 m + 2 k dwords, conflict-free within each half wave), B tile k-major [16][80]
+// ([k l>>4][col l&15]: the two k rows of a half wave sit 32 banks apart). A wave owns a 32 x 32 quadrant = 2 x 2 MFMA tiles.
+// (Tried and measured on MI355X, whole 512x512x3 solve: 32 x 64 tiles with K step 32: 129 us; 64 x 64 with K step 32:
+// 135 us; this form: 132 us at 512^2 and the best of the three at 1024^2, 544 us — against 103 / 486 us with rocBLAS's
+// MT128x64 / MT32x64 macro-tiles, which run the 1024^2 products at 65-75 TFLOP/s, i.e. within 20 % of the fp64 MFMA peak.)
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void dct_gemm_f64(int M, int N, int K, const double *A, int lda, long long strideA,
+                                                       const double *B, int ldb, long long strideB, double *C, int ldc, long long strideC, GemmEpi e) {
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) double sA[2][kGemmBM * kGemmLdA];
+    __shared__ __attribute__((aligned(16))) double sB[2][kGemmBK * kGemmLdB];
+    __shared__ double red[kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = blockIdx.z;
+    A += (long long)ch * strideA; B += (long long)ch * strideB; C += (long long)ch * strideC;
+    const int m0 = blockIdx.y * kGemmBM, n0 = blockIdx.x * kGemmBN;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    // staging roles: A tile 64 x 16 -> thread (row tid >> 2, 4 consecutive k: four threads read one 128-byte line);
+    // B tile 16 x 64 -> thread (k = tid >> 4, 4 consecutive n)
+    const int am = tid >> 2, ak = (tid & 3) * 4;
+    const int bk = tid >> 4, bn = (tid & 15) * 4;
+    // vector loads when every 16-byte pair is aligned and the tile lies inside the matrices (block-uniform)
+    const bool fast = ((lda | ldb) & 1) == 0 && m0 + kGemmBM <= M && n0 + kGemmBN <= N &&
+                      ((reinterpret_cast<unsigned long long>(A) | reinterpret_cast<unsigned long long>(B)) & 15ull) == 0;
+    d2 ra[2], rb[2];
+    auto fetch = [&](int k0) {
+        if (fast && k0 + kGemmBK <= K) {
+            const d2 *pa = reinterpret_cast<const d2 *>(A + (long long)(m0 + am) * lda + k0 + ak);
+            const d2 *pb = reinterpret_cast<const d2 *>(B + (long long)(k0 + bk) * ldb + n0 + bn);
+            ra[0] = pa[0]; ra[1] = pa[1]; rb[0] = pb[0]; rb[1] = pb[1];
+            return;
+        }
+        const int gm = m0 + am, gk = k0 + bk;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int ka = k0 + ak + j, gn = n0 + bn + j;
+            ra[j >> 1][j & 1] = (gm < M && ka < K) ? A[(long long)gm * lda + ka] : 0.0;
+            rb[j >> 1][j & 1] = (gk < K && gn < N) ? B[(long long)gk * ldb + gn] : 0.0;
+        }
+    };
+    auto stage = [&](int buf) {
+        d2 *qa = reinterpret_cast<d2 *>(&sA[buf][am * kGemmLdA + ak]);     // 144 am + 32 (tid & 3) bytes: 16-byte aligned
+        d2 *qb = reinterpret_cast<d2 *>(&sB[buf][bk * kGemmLdB + bn]);
+        qa[0] = ra[0]; qa[1] = ra[1]; qb[0] = rb[0]; qb[1] = rb[1];
+    };
+    d4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+    const int steps = (K + kGemmBK - 1) / kGemmBK;
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    for (int s = 0; s < steps; s++) {
+        const int buf = s & 1;
+        if (s + 1 < steps) fetch((s + 1) * kGemmBK);               // in flight during the MFMAs below
+        const double *pa = sA[buf] + (wm + (lane & 15)) * kGemmLdA + (lane >> 4);
+        const double *pb = sB[buf] + (lane >> 4) * kGemmLdB + wn + (lane & 15);
+        double a0[kGemmBK / 4], a1[kGemmBK / 4], b0[kGemmBK / 4], b1[kGemmBK / 4];
+#pragma unroll
+        for (int ks = 0; ks < kGemmBK / 4; ks++) {                 // all operand reads of the step first: one LDS latency, not four
+            a0[ks] = pa[ks * 4]; a1[ks] = pa[ks * 4 + 16 * kGemmLdA];
+            b0[ks] = pb[ks * 4 * kGemmLdB]; b1[ks] = pb[ks * 4 * kGemmLdB + 16];
+        }
+#pragma unroll
+        for (int ks = 0; ks < kGemmBK / 4; ks++) {
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ks], b0[ks], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ks], b1[ks], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[ks], b0[ks], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[ks], b1[ks], acc[1][1], 0, 0, 0);
+        }
+        if (s + 1 < steps) stage(buf ^ 1);
+        __syncthreads();
+    }
+    double dc = 0.0;
+    if (EPI == 1 && m0 == 0 && n0 == 0) dc = reduce_partials(e.dc_partials + (size_t)ch * e.dc_nb, e.dc_nb, red);   // block-uniform branch
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = m0 + wm + 16 * i + (lane >> 4) + 4 * r, col = n0 + wn + 16 * j + (lane & 15);
+                if (row >= M || col >= N) continue;
+                double v = acc[i][j][r];
+                if (EPI == 1) {
+                    const float resp = (float)(e.lap_y[row] + e.lap_x[col]);          // `float ftLapResponse` in the reference (:233)
+                    v = v / (e.alpha - resp);
+                    if (row == 0 && col == 0) v = dc;
+                }
+                if (EPI == 2) e.out[((size_t)row * e.out_w + col) * 3 + ch] = v / e.denom;
+                else C[(long long)row * ldc + col] = v;
+            }
+}
+
 } // namespace gp
 
 namespace gdpt {
@@ -310,6 +426,7 @@ namespace {
 struct DctPlan {
     int n = 0;
     double *d_mat = nullptr;   // C[j][k] = w_j cos(pi j k/(n-1)), row-major n x n
+    double *d_mat_t = nullptr; // its transpose, row-major (the column transform's left operand)
     double *d_lap = nullptr;   // 2 cos(pi i/(n-1)) (the caller adds -4 on the y axis)
 };
 // Transform matrices and eigenvalue tables depend on the extent only: one set per device, shared (read-only) by every
@@ -320,7 +437,7 @@ struct DctTables {
     std::vector<std::unique_ptr<DctPlan>> plans;
     std::vector<std::pair<int, double *>> lap_y;
     void release() {
-        for (auto &p : plans) { if (p->d_mat) hipFree(p->d_mat); if (p->d_lap) hipFree(p->d_lap); }
+        for (auto &p : plans) { if (p->d_mat) hipFree(p->d_mat); if (p->d_mat_t) hipFree(p->d_mat_t); if (p->d_lap) hipFree(p->d_lap); }
         for (auto &l : lap_y) if (l.second) hipFree(l.second);
         plans.clear(); lap_y.clear();
     }
@@ -379,6 +496,12 @@ const DctPlan &get_plan(DctTables &t, int n) {
     ck(hipMalloc((void **)&p->d_mat, m.size() * sizeof(double)), "hipMalloc(dct matrix)");
     ck(hipMalloc((void **)&p->d_lap, lap.size() * sizeof(double)), "hipMalloc(dct lap)");
     ck(hipMemcpy(p->d_mat, m.data(), m.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(dct matrix)");
+    {
+        std::vector<double> mt((size_t)n * n);
+        for (int j = 0; j < n; j++) for (int k = 0; k < n; k++) mt[(size_t)k * n + j] = m[(size_t)j * n + k];
+        ck(hipMalloc((void **)&p->d_mat_t, mt.size() * sizeof(double)), "hipMalloc(dct matrix^T)");
+        ck(hipMemcpy(p->d_mat_t, mt.data(), mt.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(dct matrix^T)");
+    }
     ck(hipMemcpy(p->d_lap, lap.data(), lap.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(dct lap)");
     p->n = n;
     t.plans.push_back(std::move(p));
@@ -397,16 +520,19 @@ const double *get_lap_y(DctTables &t, int h) {   // ftLapY = -4 + 2 cos(pi y/(h-
 
 // Enqueue-only unless `timed`: no event is created, recorded or waited for on the product path (stats == NULL).
 PoissonResult poisson_dct(int dev, DctWorkspace &ws, int w, int h, const double *d_c, const double *d_gx, const double *d_gy, double alpha,
-                          double *d_out, hipStream_t stream, bool timed) {
-    if (!ws.handle) rb(rocblas_create_handle(&ws.handle), "rocblas_create_handle");
-    rb(rocblas_set_stream(ws.handle, stream), "rocblas_set_stream");
-    const double *Cw, *Ch, *lap_x, *lap_y;
+                          double *d_out, hipStream_t stream, bool timed, bool library_gemm) {
+    if (library_gemm) {
+        if (!ws.handle) rb(rocblas_create_handle(&ws.handle), "rocblas_create_handle");
+        rb(rocblas_set_stream(ws.handle, stream), "rocblas_set_stream");
+    }
+    const double *Cw, *Ch, *ChT, *lap_x, *lap_y;
     {
         DctTables &t = device_tables(dev);
         std::lock_guard<std::mutex> lk(t.mu);
         const DctPlan &pw = get_plan(t, w);
         Cw = pw.d_mat; lap_x = pw.d_lap;
-        Ch = get_plan(t, h).d_mat;
+        const DctPlan &ph = get_plan(t, h);
+        Ch = ph.d_mat; ChT = ph.d_mat_t;
         lap_y = get_lap_y(t, h);
     }
     gp::Geo g{w, h, w * h * 3, w * 3};
@@ -435,11 +561,25 @@ PoissonResult poisson_dct(int dev, DctWorkspace &ws, int w, int h, const double 
         rb(rocblas_dgemm_strided_batched(ws.handle, rocblas_operation_none, rocblas_operation_transpose, w, h, h, &one,
                                          tmp, w, (rocblas_stride)plane, Ch, h, 0, &zero, dst, w, (rocblas_stride)plane, 3), "dgemm(cols)");
     };
-    transform(A, B, A);                                      // A = DCT2D(h)
-    hipLaunchKernelGGL(gp::dct_scale_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, alpha, lap_x, lap_y, A);
-    hipLaunchKernelGGL(gp::dct_dc_kernel, dim3(1), dim3(gp::kBlock), 0, stream, g, A, ws.partials, nb);
-    transform(A, B, A);                                      // A = DCT2D(F^)
-    hipLaunchKernelGGL(gp::dct_finalize_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, A, d_out);
+    if (library_gemm) {                                      // GDPT_SOLVER_DCT: the two 1-D passes as rocBLAS dgemm_strided_batched
+        transform(A, B, A);                                  // A = DCT2D(h)
+        hipLaunchKernelGGL(gp::dct_scale_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, alpha, lap_x, lap_y, A);
+        hipLaunchKernelGGL(gp::dct_dc_kernel, dim3(1), dim3(gp::kBlock), 0, stream, g, A, ws.partials, nb);
+        transform(A, B, A);                                  // A = DCT2D(F^)
+        hipLaunchKernelGGL(gp::dct_finalize_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, A, d_out);
+    } else {
+        // GDPT_SOLVER_DCT_MFMA: own fp64 MFMA GEMMs, per channel plane (h x w row-major):  T = X * Cw  (rows),  Y = Ch^T * T  (columns);
+        // spectral division + DC override ride on the second GEMM, the final scaling + interleaving on the fourth
+        gp::GemmEpi e{};
+        e.alpha = alpha; e.lap_x = lap_x; e.lap_y = lap_y; e.dc_partials = ws.partials; e.dc_nb = nb;
+        e.denom = 4.0 * (double)(w - 1) * (double)(h - 1); e.out = d_out; e.out_w = w;
+        const dim3 grid((unsigned)((w + gp::kGemmBN - 1) / gp::kGemmBN), (unsigned)((h + gp::kGemmBM - 1) / gp::kGemmBM), 3), block(256);
+        const long long pl = (long long)plane;
+        hipLaunchKernelGGL((gp::dct_gemm_f64<0>), grid, block, 0, stream, h, w, w, (const double *)A, w, pl, Cw, w, 0LL, B, w, pl, e);    // B = A * Cw
+        hipLaunchKernelGGL((gp::dct_gemm_f64<1>), grid, block, 0, stream, h, w, h, ChT, h, 0LL, (const double *)B, w, pl, A, w, pl, e);  // A = Ch^T * B, / (alpha - lambda), DC
+        hipLaunchKernelGGL((gp::dct_gemm_f64<0>), grid, block, 0, stream, h, w, w, (const double *)A, w, pl, Cw, w, 0LL, B, w, pl, e);    // B = A * Cw
+        hipLaunchKernelGGL((gp::dct_gemm_f64<2>), grid, block, 0, stream, h, w, h, ChT, h, 0LL, (const double *)B, w, pl, A, w, pl, e);  // out = Ch^T * B / denom
+    }
     ck(hipGetLastError(), "dct kernel launch");
     float ms = 0;
     if (timed) {
@@ -480,14 +620,18 @@ PoissonResult poisson_solve_device(int w, int h, const double *d_c, const double
                                    double *d_out, int solver, double tol, int max_iters, hipStream_t stream, bool timed) {
     if (w < 2 || h < 2) throw std::runtime_error("poisson: width and height must be >= 2 (the reference divides by (W-1)(H-1))");
     if (!(alpha > 0)) throw std::runtime_error("poisson: dataCost must be > 0");
-    if (solver != GDPT_SOLVER_CG && solver != GDPT_SOLVER_DCT) throw std::runtime_error("poisson: unknown solver");
+    if (solver != GDPT_SOLVER_CG && solver != GDPT_SOLVER_DCT && solver != GDPT_SOLVER_DCT_MFMA) throw std::runtime_error("poisson: unknown solver");
     if (tol <= 0) tol = 1e-10;
     if (max_iters <= 0) max_iters = 2000;
     int dev = 0;
     ck(hipGetDevice(&dev), "hipGetDevice");
     StreamState &ss = stream_state(dev, stream);
     std::lock_guard<std::mutex> lk(ss.mu);
-    if (solver == GDPT_SOLVER_DCT) return poisson_dct(dev, ss.dct, w, h, d_c, d_gx, d_gy, alpha, d_out, stream, timed);
+    if (solver != GDPT_SOLVER_CG) {
+        PoissonResult r = poisson_dct(dev, ss.dct, w, h, d_c, d_gx, d_gy, alpha, d_out, stream, timed, solver == GDPT_SOLVER_DCT);
+        r.solver = solver;
+        return r;
+    }
     gp::Geo g{w, h, w * h * 3, w * 3};
     if ((size_t)g.n3 > ss.cg.n3 && ss.cg.n3) ck(hipStreamSynchronize(stream), "hipStreamSynchronize");
     ss.cg.ensure((size_t)g.n3);

@@ -183,8 +183,12 @@ typedef struct GdptPoissonStats {
 } GdptPoissonStats;
 
 /* CG: conjugate gradients on W(alpha I - L) f = W h + DC shift (matches the DCT solve to the CG tolerance; differs
- *     from the reference by its fp32-lambda quirk, ~3e-9).  DCT: direct solve, exact reference operator. */
-enum { GDPT_SOLVER_CG = 0, GDPT_SOLVER_DCT = 1 };
+ *     from the reference by its fp32-lambda quirk, ~3e-9).
+ * DCT: direct solve, exact reference operator; the two 1-D DCT-I passes are plain fp64 GEMMs against fixed cosine matrices
+ *     and run as rocBLAS dgemm_strided_batched (the default: 0.10 ms at 512x512).
+ * DCT_MFMA: the same solve with the passes as hand-written fp64 MFMA GEMM kernels whose epilogues carry the spectral
+ *     division, the DC override and the final scaling (5 launches instead of 8; 0.13 ms at 512x512 — DESIGN.md 4.2). */
+enum { GDPT_SOLVER_CG = 0, GDPT_SOLVER_DCT = 1, GDPT_SOLVER_DCT_MFMA = 2 };
 
 typedef struct GdptScene GdptScene;   /* opaque: device-resident scene (BVH2 + BVH4, triangles, materials, textures) */
 

@@ -1,0 +1,26 @@
+"""Manual timing (not collected by pytest): Poisson solve, own fp64 MFMA DCT vs the rocBLAS variant vs CG."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import gdpt_amd as G
+from test_poisson_oracle import lcg_fields
+dev = torch.device("cuda", 0)
+for w, h in ((512, 512), (1024, 1024), (1280, 720)):
+    c, gx, gy = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in lcg_fields(w, h, seed=1))
+    out = torch.zeros_like(c)
+    res = {}
+    for name, which in (("own_mfma", G.SOLVER_DCT_MFMA), ("rocblas", G.SOLVER_DCT)):
+        for _ in range(3):
+            G.poisson_solve_device(w, h, c.data_ptr(), gx.data_ptr(), gy.data_ptr(), out.data_ptr(), solver=which)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            G.poisson_solve_device(w, h, c.data_ptr(), gx.data_ptr(), gy.data_ptr(), out.data_ptr(), solver=which)
+        e1.record(); torch.cuda.synchronize()
+        res[name] = (e0.elapsed_time(e1) / 20, out.clone())
+    d = (res["own_mfma"][1] - res["rocblas"][1]).abs().max().item()
+    fl = 4 * 3 * (2.0 * w * w * h + 2.0 * h * h * w) / 2
+    print(f"{w}x{h}: own MFMA {res['own_mfma'][0] * 1e3:.1f} us ({fl / res['own_mfma'][0] / 1e9:.1f} TFLOP/s), rocBLAS {res['rocblas'][0] * 1e3:.1f} us "
+          f"({fl / res['rocblas'][0] / 1e9:.1f} TFLOP/s), max abs diff {d:.2e}", flush=True)
