@@ -288,6 +288,7 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     v.all_textures_constant = 1;
     for (auto &m : materials) for (auto &t : m.tex) if (t.type != GDPT_TEX_CONSTANT) v.all_textures_constant = 0;
     for (auto &m : materials) {
+        sc->material_mask |= 1u << m.type;
         if (m.type != GDPT_MAT_LAMBERTIAN) sc->lambert_only = false;
         if (m.type == GDPT_MAT_ROUGHPLASTIC || m.type == GDPT_MAT_ROUGHDIELECTRIC) sc->has_rough = true;
         if (m.type == GDPT_MAT_DISNEY_GLASS || m.type == GDPT_MAT_DISNEY_BSDF || m.type == GDPT_MAT_ROUGHDIELECTRIC) sc->one_sided = false;   // two-sided lobes
@@ -418,9 +419,12 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.counters = sc->d_counters;
     rl.count_traversal = stats && stats->nodes_visited == ~0ull;   // request flag: caller presets nodes_visited = UINT64_MAX
     rl.one_sided_materials = sc->one_sided && !sc->has_rough; rl.lambert_only = sc->lambert_only;
+    rl.material_mask = sc->material_mask;
+    rl.wide_stack_need = sc->wide_stack_need; rl.num_materials = sc->view.num_materials;
     rl.scene_fits_lds = gdpt::scene_fits_lds(sc->view.num_nodes, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->bvh_depth);
     // A/B overrides of the parity tests (include/gdpt_debug.h); every default below is the product path
     auto env_int = [](const char *name, int def) { return gdpt::debug_knob_int(name, def); };
+    if (env_int("full_material_switch", 0)) rl.material_mask = 0x1FFu;
     rl.force_eager = env_int("force_eager", 0) != 0;
     rl.thresh_a = env_int("keep_frac", -1); rl.thresh_c = env_int("search_frac", -1);
     rl.force_log2k = env_int("log2k", -1);

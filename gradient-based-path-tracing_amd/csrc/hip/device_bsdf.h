@@ -494,48 +494,52 @@ GD bool rd_sample(const Ctx &c, const GdptMaterial &m, D3 in, D2 ruv, double rw,
 // use them go to the kernels built with ROUGH = true.
 // TWOSIDED = false likewise drops DisneyGlass / DisneyBSDF (the two heaviest lobes): the one-sided GradPath lane
 // machine never meets them.
-template <bool ROUGH = true, bool TWOSIDED = true>
+// MASK: bit t set = material type t may occur (decided from the scene at upload, gdpt_scene_upload): a kernel built for
+// {Lambertian, DisneyGlass} does not carry DisneyBSDF's five inlined lobes through its register allocation.
+constexpr unsigned kAllMaterials = 0x1FFu;
+template <unsigned MASK, int T> GD constexpr bool mat_on() { return (MASK >> T) & 1u; }
+template <bool ROUGH = true, bool TWOSIDED = true, unsigned MASK = kAllMaterials>
 GD D3 bsdf_eval(const DevSceneView &sv, const GdptMaterial &m, D3 in, D3 out, const Vertex &v) {
     Ctx c{sv, v};
     switch (m.type) {
         case GDPT_MAT_ROUGHPLASTIC: if (ROUGH) return rp_eval(c, m, in, out); else return splat(0);
         case GDPT_MAT_ROUGHDIELECTRIC: if (ROUGH) return rd_eval(c, m, in, out); else return splat(0);
         case GDPT_MAT_LAMBERTIAN: return lambert_eval(c, m.tex[0], in, out);
-        case GDPT_MAT_DISNEY_DIFFUSE: return dd_eval(c, m.tex[0], m.tex[1], m.tex[2], in, out);
-        case GDPT_MAT_DISNEY_METAL: return dm_eval(c, T3(c, m.tex[0]), m.tex[1], m.tex[2], in, out);
-        case GDPT_MAT_DISNEY_GLASS: if (TWOSIDED) return dg_eval(c, m.tex[0], m.tex[1], m.tex[2], m.eta, in, out); else return splat(0);
-        case GDPT_MAT_DISNEY_CLEARCOAT: return cc_eval(c, m.tex[0], in, out);
-        case GDPT_MAT_DISNEY_SHEEN: return sh_eval(c, m.tex[0], m.tex[1], in, out);
-        case GDPT_MAT_DISNEY_BSDF: if (TWOSIDED) return db_eval(c, m, in, out); else return splat(0);
+        case GDPT_MAT_DISNEY_DIFFUSE: if (mat_on<MASK, GDPT_MAT_DISNEY_DIFFUSE>()) return dd_eval(c, m.tex[0], m.tex[1], m.tex[2], in, out); else return splat(0);
+        case GDPT_MAT_DISNEY_METAL: if (mat_on<MASK, GDPT_MAT_DISNEY_METAL>()) return dm_eval(c, T3(c, m.tex[0]), m.tex[1], m.tex[2], in, out); else return splat(0);
+        case GDPT_MAT_DISNEY_GLASS: if (TWOSIDED && mat_on<MASK, GDPT_MAT_DISNEY_GLASS>()) return dg_eval(c, m.tex[0], m.tex[1], m.tex[2], m.eta, in, out); else return splat(0);
+        case GDPT_MAT_DISNEY_CLEARCOAT: if (mat_on<MASK, GDPT_MAT_DISNEY_CLEARCOAT>()) return cc_eval(c, m.tex[0], in, out); else return splat(0);
+        case GDPT_MAT_DISNEY_SHEEN: if (mat_on<MASK, GDPT_MAT_DISNEY_SHEEN>()) return sh_eval(c, m.tex[0], m.tex[1], in, out); else return splat(0);
+        case GDPT_MAT_DISNEY_BSDF: if (TWOSIDED && mat_on<MASK, GDPT_MAT_DISNEY_BSDF>()) return db_eval(c, m, in, out); else return splat(0);
         default: return splat(0);
     }
 }
-template <bool ROUGH = true, bool TWOSIDED = true>
+template <bool ROUGH = true, bool TWOSIDED = true, unsigned MASK = kAllMaterials>
 GD double bsdf_pdf(const DevSceneView &sv, const GdptMaterial &m, D3 in, D3 out, const Vertex &v) {
     Ctx c{sv, v};
     switch (m.type) {
         case GDPT_MAT_ROUGHPLASTIC: if (ROUGH) return rp_pdf(c, m, in, out); else return 0;
         case GDPT_MAT_ROUGHDIELECTRIC: if (ROUGH) return rd_pdf(c, m, in, out); else return 0;
         case GDPT_MAT_LAMBERTIAN: case GDPT_MAT_DISNEY_DIFFUSE: case GDPT_MAT_DISNEY_SHEEN: return cos_pdf(c, in, out);
-        case GDPT_MAT_DISNEY_METAL: return dm_pdf(c, m.tex[1], m.tex[2], in, out);
-        case GDPT_MAT_DISNEY_GLASS: if (TWOSIDED) return dg_pdf(c, m.tex[1], m.tex[2], m.eta, in, out); else return 0;
-        case GDPT_MAT_DISNEY_CLEARCOAT: return cc_pdf(c, m.tex[0], in, out);
-        case GDPT_MAT_DISNEY_BSDF: if (TWOSIDED) return db_pdf(c, m, in, out); else return 0;
+        case GDPT_MAT_DISNEY_METAL: if (mat_on<MASK, GDPT_MAT_DISNEY_METAL>()) return dm_pdf(c, m.tex[1], m.tex[2], in, out); else return 0;
+        case GDPT_MAT_DISNEY_GLASS: if (TWOSIDED && mat_on<MASK, GDPT_MAT_DISNEY_GLASS>()) return dg_pdf(c, m.tex[1], m.tex[2], m.eta, in, out); else return 0;
+        case GDPT_MAT_DISNEY_CLEARCOAT: if (mat_on<MASK, GDPT_MAT_DISNEY_CLEARCOAT>()) return cc_pdf(c, m.tex[0], in, out); else return 0;
+        case GDPT_MAT_DISNEY_BSDF: if (TWOSIDED && mat_on<MASK, GDPT_MAT_DISNEY_BSDF>()) return db_pdf(c, m, in, out); else return 0;
         default: return 0;
     }
 }
-template <bool ROUGH = true, bool TWOSIDED = true>
+template <bool ROUGH = true, bool TWOSIDED = true, unsigned MASK = kAllMaterials>
 GD bool bsdf_sample(const DevSceneView &sv, const GdptMaterial &m, D3 in, const Vertex &v, D2 ruv, double rw, BsdfSample &s) {
     Ctx c{sv, v};
     switch (m.type) {
         case GDPT_MAT_ROUGHPLASTIC: if (ROUGH) return rp_sample(c, m, in, ruv, rw, s); else return false;
         case GDPT_MAT_ROUGHDIELECTRIC: if (ROUGH) return rd_sample(c, m, in, ruv, rw, s); else return false;
         case GDPT_MAT_LAMBERTIAN: case GDPT_MAT_DISNEY_SHEEN: return cos_sample(c, in, ruv, 1.0, s);
-        case GDPT_MAT_DISNEY_DIFFUSE: return dd_sample(c, m.tex[1], in, ruv, s);
-        case GDPT_MAT_DISNEY_METAL: return dm_sample(c, m.tex[1], m.tex[2], in, ruv, s);
-        case GDPT_MAT_DISNEY_GLASS: if (TWOSIDED) return dg_sample(c, m.tex[1], m.eta, in, ruv, rw, s); else return false;
-        case GDPT_MAT_DISNEY_CLEARCOAT: return cc_sample(c, m.tex[0], in, ruv, s);
-        case GDPT_MAT_DISNEY_BSDF: if (TWOSIDED) return db_sample(c, m, in, ruv, rw, s); else return false;
+        case GDPT_MAT_DISNEY_DIFFUSE: if (mat_on<MASK, GDPT_MAT_DISNEY_DIFFUSE>()) return dd_sample(c, m.tex[1], in, ruv, s); else return false;
+        case GDPT_MAT_DISNEY_METAL: if (mat_on<MASK, GDPT_MAT_DISNEY_METAL>()) return dm_sample(c, m.tex[1], m.tex[2], in, ruv, s); else return false;
+        case GDPT_MAT_DISNEY_GLASS: if (TWOSIDED && mat_on<MASK, GDPT_MAT_DISNEY_GLASS>()) return dg_sample(c, m.tex[1], m.eta, in, ruv, rw, s); else return false;
+        case GDPT_MAT_DISNEY_CLEARCOAT: if (mat_on<MASK, GDPT_MAT_DISNEY_CLEARCOAT>()) return cc_sample(c, m.tex[0], in, ruv, s); else return false;
+        case GDPT_MAT_DISNEY_BSDF: if (TWOSIDED && mat_on<MASK, GDPT_MAT_DISNEY_BSDF>()) return db_sample(c, m, in, ruv, rw, s); else return false;
         default: return false;
     }
 }

@@ -68,6 +68,7 @@ struct KernelArgs {
     int row_begin, row_end, max_depth;
     int thresh_a, thresh_c;
     int count;
+    int stack_levels;                  // scenes walked from HBM: traversal-stack slots per lane in dynamic LDS (= the tree's bound)
     int num_chunks;                    // work items per pixel: chunk c covers samples [chunk_begin[c], chunk_begin[c+1])
     long long num_slots;               // pixel slots of the band: tiles * 256 (ragged edge tiles keep all 256)
     long long num_items;               // num_slots * num_chunks (< 2^32); item = chunk * num_slots + slot ("tier-major")
@@ -336,13 +337,13 @@ GD bool occluded_ctx(const DevSceneView &sv, const TraceCtx &tx, const Ray &ray,
 // ------------------------------------------------------------------------------------------------
 // material dispatch: Lambertian-only scenes get the three-line lobe inline, others the full switch
 // ------------------------------------------------------------------------------------------------
-template <bool LAMBERT, bool ROUGH = false, bool TWOSIDED = false>
+template <bool LAMBERT, bool ROUGH = false, bool TWOSIDED = false, unsigned MASK = kAllMaterials>
 GD bool mat_sample(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D2 ruv, double rw, BsdfSample &s) {
     if (LAMBERT) { Ctx c{sv, v}; return cos_sample(c, in, ruv, 1.0, s); }
-    return bsdf_sample<ROUGH, TWOSIDED>(sv, tx.materials[v.material_id], in, v, ruv, rw, s);
+    return bsdf_sample<ROUGH, TWOSIDED, MASK>(sv, tx.materials[v.material_id], in, v, ruv, rw, s);
 }
 // eval (f*|cos|) and solid-angle pdf together
-template <bool LAMBERT, bool ROUGH = false, bool TWOSIDED = false>
+template <bool LAMBERT, bool ROUGH = false, bool TWOSIDED = false, unsigned MASK = kAllMaterials>
 GD void mat_eval_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D3 out, D3 &f, double &pdf) {
     if (LAMBERT) {
         // src/materials/lambertian.inl:1-33 — eval and pdf share the clamped cosine
@@ -354,8 +355,8 @@ GD void mat_eval_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v
         return;
     }
     const GdptMaterial &m = tx.materials[v.material_id];
-    f = bsdf_eval<ROUGH, TWOSIDED>(sv, m, in, out, v);
-    pdf = bsdf_pdf<ROUGH, TWOSIDED>(sv, m, in, out, v);
+    f = bsdf_eval<ROUGH, TWOSIDED, MASK>(sv, m, in, out, v);
+    pdf = bsdf_pdf<ROUGH, TWOSIDED, MASK>(sv, m, in, out, v);
 }
 template <bool LAMBERT>
 GD double mat_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D3 out) {
@@ -642,6 +643,9 @@ GD void reduce_and_store(const KernelArgs &a, Accum &acc, int K, bool writer, in
     }
 }
 
+// dynamic LDS of the kernels that walk the scene from HBM: the traversal stack, sized from the tree's own bound
+inline size_t hbm_dynamic_lds(const KernelArgs &a) { return (size_t)a.stack_levels * kBlock * sizeof(int); }
+
 // Copies nodes (BVH2 or wide form), primitive records, the shading table and the materials into LDS (small scenes)
 // and returns the trace context of this lane.
 template <bool LDS_SCENE, bool WIDE>
@@ -671,6 +675,10 @@ GD TraceCtx setup_trace(const DevSceneView &sv, unsigned char *s_scene, int *s_s
     }
     return tx;
 }
+// (Tried: a copy of the material table in LDS behind the stack for scenes walked from HBM — every texture / parameter read
+// of every BSDF call goes through that table. Because the choice is made at run time the table pointer becomes a generic
+// pointer and every read a flat_load waiting on both counters: the Disney scenes ran 5-10 % slower, so the table stays in
+// HBM / L1 for them; only the stack is sized from the tree's own bound.)
 
 // Work items of the persistent kernels: item = chunk * num_slots + slot, slot = tile * 256 + pixel_in_tile, tiles = the
 // reference's 16x16 tiles of the band in row-major order (ragged edge tiles keep all 256 slots; their outside pixels
@@ -733,11 +741,14 @@ struct WaveQueue {
 // so the result does not depend on which lane processed what, or when.
 template <bool LAMBERT, bool LDS_SCENE, bool WIDE, bool WW, bool STAMPED = false>
 __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv, KernelArgs a) {
-    constexpr int kLevels = LDS_SCENE ? kLdsSceneLevels : GDPT_BVH_MAX_DEPTH;
-    __shared__ int s_stack[kLevels * kBlock];
+    // LDS-resident scenes: fixed 12-slot stack + the scene copy. Scenes walked from HBM: dynamic LDS = a.stack_levels stack
+    // slots per lane (the tree's own bound, not the builder's maximum of 32).
+    __shared__ int s_stack_fixed[LDS_SCENE ? kLdsSceneLevels * kBlock : 1];
     __shared__ __attribute__((aligned(16))) unsigned char s_scene[LDS_SCENE ? kLdsSceneBytes : 16];
     __shared__ double s_acc[15 * kBlock];
     __shared__ double s_priv[kPrivDoubles * kBlock];
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    int *s_stack = LDS_SCENE ? s_stack_fixed : (int *)s_dyn;
     const int tid = threadIdx.x;
     TraceCtx tx = setup_trace<LDS_SCENE, WIDE>(sv, s_scene, s_stack, tid, kBlock, a.count != 0);
     const int W = sv.cam.width;
@@ -1046,7 +1057,7 @@ void launch_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3
 void launch_phases_lambert_stamped(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, hipStream_t stream);   // diagnostic build
 void launch_reduce_partials(const DevSceneView &sv, const gd::KernelArgs &a, hipStream_t stream);
 void launch_phases_general(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lds_wide, hipStream_t stream);
-void launch_phases_twosided(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, void *bounce_log, hipStream_t stream);
+void launch_phases_twosided(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, unsigned material_mask, void *bounce_log, hipStream_t stream);
 void launch_tile_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
 void launch_tile_phases_general(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
 void launch_eager(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, hipStream_t stream);

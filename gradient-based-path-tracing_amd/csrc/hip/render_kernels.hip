@@ -115,6 +115,9 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
             // persistent lanes pulling (pixel, chunk) items: >= 4 samples per item, at most 8 items per pixel
             set_chunks(a, rl, W, rows, sv.cam.height);
             if (a.num_items >= (1LL << 32)) throw std::runtime_error("launch_render: image band too large for the 32-bit work queue");
+            // scenes walked from HBM: stack slots = the tree's own bound (host-verified at upload)
+            a.stack_levels = rl.wide_stack_need > 0 ? rl.wide_stack_need : GDPT_BVH_MAX_DEPTH;
+            if (a.stack_levels > GDPT_BVH_MAX_DEPTH) throw std::runtime_error("launch_render: traversal stack bound exceeds the builder's maximum");
             a.partials = rl.partials; a.queue_head = rl.queue_head;
             if (!a.partials || !a.queue_head) throw std::runtime_error("launch_render: work-queue buffers missing");
             hipError_t me = hipMemsetAsync(a.queue_head, 0, sizeof(unsigned long long), stream);
@@ -125,7 +128,7 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
                 run_wavefront(sv, a, rl, stream);
             } else if (rl.two_sided_machine) {
                 if (!rl.bounce_log || rl.bounce_log_bytes < twosided_log_bytes(blocks)) throw std::runtime_error("launch_render: bounce log missing");
-                launch_phases_twosided(sv, a, grid, rl.scene_fits_lds && rl.lds_wide, rl.bounce_log, stream);
+                launch_phases_twosided(sv, a, grid, rl.scene_fits_lds && rl.lds_wide, rl.material_mask, rl.bounce_log, stream);
             } else if (rl.lambert_only && rl.stamped && (!rl.scene_fits_lds || rl.lds_wide)) launch_phases_lambert_stamped(sv, a, grid, rl.scene_fits_lds, stream);
             else if (rl.lambert_only) launch_phases_lambert(sv, a, grid, rl.scene_fits_lds, rl.lds_wide, stream);
             else launch_phases_general(sv, a, grid, rl.scene_fits_lds, rl.lds_wide, stream);

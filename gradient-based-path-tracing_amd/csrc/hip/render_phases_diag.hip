@@ -4,6 +4,6 @@
 namespace gdpt {
 void launch_phases_lambert_stamped(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, hipStream_t stream) {
     if (lds) hipLaunchKernelGGL((gd::gdpt_render_phases<true, true, true, true, true>), grid, dim3(gd::kBlock), 0, stream, sv, a);
-    else hipLaunchKernelGGL((gd::gdpt_render_phases<true, false, true, true, true>), grid, dim3(gd::kBlock), 0, stream, sv, a);
+    else hipLaunchKernelGGL((gd::gdpt_render_phases<true, false, true, true, true>), grid, dim3(gd::kBlock), gd::hbm_dynamic_lds(a), stream, sv, a);
 }
 } // namespace gdpt

@@ -5,7 +5,7 @@ namespace gdpt {
 void launch_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lds_wide, hipStream_t stream) {
     if (lds && lds_wide) hipLaunchKernelGGL((gd::gdpt_render_phases<true, true, true, true>), grid, dim3(gd::kBlock), 0, stream, sv, a);
     else if (lds) hipLaunchKernelGGL((gd::gdpt_render_phases<true, true, false, false>), grid, dim3(gd::kBlock), 0, stream, sv, a);
-    else hipLaunchKernelGGL((gd::gdpt_render_phases<true, false, true, true>), grid, dim3(gd::kBlock), 0, stream, sv, a);
+    else hipLaunchKernelGGL((gd::gdpt_render_phases<true, false, true, true>), grid, dim3(gd::kBlock), gd::hbm_dynamic_lds(a), stream, sv, a);
 }
 void launch_reduce_partials(const DevSceneView &sv, const gd::KernelArgs &a, hipStream_t stream) {
     const long long nslots = a.num_slots;

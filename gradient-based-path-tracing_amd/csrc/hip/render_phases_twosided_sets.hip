@@ -1,0 +1,9 @@
+// Two-sided lane machine built for a small material set (render_twosided.h: kSetGlass), scenes walked from HBM.
+// (A {Lambertian, DisneyBSDF} build was measured too: 197 instead of 318 spilled VGPRs and 6 % SLOWER than the full switch
+// on the same box, tests/ab_twosided.py — spills are not what binds these kernels — so DisneyBSDF scenes keep the full one.)
+#include "render_twosided.h"
+namespace gdpt {
+void launch_phases_twosided_glass(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, void *bounce_log, hipStream_t stream) {
+    hipLaunchKernelGGL((gd::gdpt_render_twosided<false, gd::kSetGlass>), grid, dim3(gd::kBlock), gd::hbm_dynamic_lds(a), stream, sv, a, (gd::BounceLog *)bounce_log);
+}
+} // namespace gdpt

@@ -20,7 +20,7 @@ namespace gd {
 
 constexpr int S_REPLAY = 5;            // after S_DONE = 4: an offset re-sampling its primary vertex, no pending ray
 constexpr int kLogCap = 1024;
-struct BounceLog { double p2; int mat; int pad; };   // p2 < 0: the iteration broke at pdf <= 0 (before any update)
+struct BounceLog { double p2; int mat; int pad; };   // p2 < 0: the iteration broke at pdf <= 0 (before any update); log[it * kBlock] = iteration `it` of this lane
 
 // LDS slot of a lane (doubles, stride kBlock): 0..2 radiance, 3 eta_scale, 4..7 filter cache
 struct LanePriv2 {
@@ -38,7 +38,7 @@ struct LanePriv2 {
 GD int n_iter(const Lane &L) { return (int)((unsigned)L.mats >> 12); }
 GD void set_n_iter(Lane &L, int n) { L.mats = (L.mats & 0xFFF) | (n << 12); }
 
-template <class ACC>
+template <unsigned MASK, class ACC>
 GD void lane_step2(const DevSceneView &sv, const TraceCtx &tx, int max_depth, double spp, int x, int y, unsigned long long base,
                    Lane &L, Trav &tv, LanePriv2 &lp, ACC &acc, LaneCounters &lc, BounceLog *log) {
     const DevCamera &cam = sv.cam;
@@ -75,7 +75,7 @@ GD void lane_step2(const DevSceneView &sv, const TraceCtx &tx, int max_depth, do
         if (hit) { D3 dl = nv.position - ray.org; G = fabs(dot(ray.dir, nv.gn)) / dot(dl, dl); }   // :746-753
         const D3 f = L.f;
         const double p2 = L.pdf * G;                                                // :766
-        if (it < kLogCap) log[it].p2 = p2;
+        if (it < kLogCap) log[it * kBlock].p2 = p2;
         L.contrib = L.contrib * f * G; L.prob *= p2;                                // :769-770
         if (hit && nv.light_id >= 0) {                                              // :971-980
             D3 Le = emission(sv, nv, -ray.dir);
@@ -118,7 +118,7 @@ GD void lane_step2(const DevSceneView &sv, const TraceCtx &tx, int max_depth, do
         const int r = L.kc >> 2;
         if (r >= n_iter(L) || r >= kLogCap) { off_done = true; off_alive = (r >= n_iter(L)); }     // all iterations replayed
         else {
-            const BounceLog e = log[r];
+            const BounceLog e = log[r * kBlock];
             if (nv.material_id != e.mat) { off_done = true; off_alive = false; }    // :607-612
             else if (e.p2 < 0) off_done = true;                                     // the base broke at pdf <= 0: no re-sampling
             else { need_resample = true; log_p2 = e.p2; }
@@ -137,8 +137,8 @@ GD void lane_step2(const DevSceneView &sv, const TraceCtx &tx, int max_depth, do
         L.rng_state = r.state;
         if (act == ACT_BOUNCE) lc.bounces++;
         const D3 dir_view = (act == ACT_BOUNCE) ? -ray.dir : -L.f;
-        sampled = mat_sample<false, false, true>(sv, tx, nv, dir_view, ruv, rw, bs);
-        if (sampled) mat_eval_pdf<false, false, true>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
+        sampled = mat_sample<false, false, true, MASK>(sv, tx, nv, dir_view, ruv, rw, bs);
+        if (sampled) mat_eval_pdf<false, false, true, MASK>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
     }
     if (need_resample) {
         if (!sampled || pdf <= 0.0) { off_done = true; off_alive = false; }         // :773-959
@@ -160,7 +160,7 @@ GD void lane_step2(const DevSceneView &sv, const TraceCtx &tx, int max_depth, do
         const int it = L.num_vertices - 3;
         if (!sampled) act = ACT_NEXT_SAMPLE;                                        // :545-548: GraidentPTRadiance{}
         else {
-            if (it < kLogCap) { log[it].mat = nv.material_id; if (pdf <= 0) log[it].p2 = -1.0; }
+            if (it < kLogCap) { log[it * kBlock].mat = nv.material_id; if (pdf <= 0) log[it * kBlock].p2 = -1.0; }
             set_n_iter(L, min(it + 1, kLogCap));
             if (pdf <= 0) act = ACT_OFFSETS;                                        // :760-763
             else {
@@ -193,13 +193,18 @@ GD void lane_step2(const DevSceneView &sv, const TraceCtx &tx, int max_depth, do
     if (lane_tracing(L.st)) trav_init(sv, tv, __builtin_huge_val());      // a fresh pending ray (S_REPLAY keeps the offset's hit)
 }
 
-template <bool LDS_SCENE>
+// Material set the kernel can be built for (bit t = material type t, include/gdpt.h): the test scenes pair ONE Disney lobe
+// with Lambertian walls, and a kernel that need not carry DisneyBSDF's five inlined lobes is a much smaller register
+// allocation problem (42 instead of 318 spilled VGPRs; +5 % on the glass scene).
+constexpr unsigned kSetGlass = (1u << GDPT_MAT_LAMBERTIAN) | (1u << GDPT_MAT_DISNEY_GLASS);
+template <bool LDS_SCENE, unsigned MASK = kAllMaterials>
 __global__ __launch_bounds__(kBlock, 2) void gdpt_render_twosided(DevSceneView sv, KernelArgs a, BounceLog *logs) {
-    constexpr int kLevels = LDS_SCENE ? kLdsSceneLevels : GDPT_BVH_MAX_DEPTH;
-    __shared__ int s_stack[kLevels * kBlock];
+    __shared__ int s_stack_fixed[LDS_SCENE ? kLdsSceneLevels * kBlock : 1];
     __shared__ __attribute__((aligned(16))) unsigned char s_scene[LDS_SCENE ? kLdsSceneBytes : 16];
     __shared__ double s_acc[15 * kBlock];
     __shared__ double s_priv[kPrivDoubles * kBlock];
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];       // HBM scenes: the traversal stack (render_device.h)
+    int *s_stack = LDS_SCENE ? s_stack_fixed : (int *)s_dyn;
     const int tid = threadIdx.x;
     TraceCtx tx = setup_trace<LDS_SCENE, true>(sv, s_scene, s_stack, tid, kBlock, a.count != 0);
     const int W = sv.cam.width;
@@ -207,7 +212,9 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_twosided(DevSceneView s
     AccLds acc; acc.slot = s_acc + tid; acc.stride = kBlock;
     acc.init();
     LanePriv2 lp; lp.slot = s_priv + tid; lp.stride = kBlock;
-    BounceLog *log = logs + ((size_t)blockIdx.x * kBlock + tid) * kLogCap;
+    // lane-interleaved: entry `it` of lane `tid` sits at it * kBlock + tid of the block's slab, so the 64 lanes of a wave
+    // touch one contiguous kilobyte per logged iteration (a per-lane 16 KB stride made every access its own cache line)
+    BounceLog *log = logs + (size_t)blockIdx.x * kBlock * kLogCap + tid;
     LaneCounters lc = {0, 0, 0};
     TraceCounters tc = {0, 0, 0, 0, 0, 0};
     Lane L;
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_twosided(DevSceneView s
         trace_pending<TraceCfg<true, true, !LDS_SCENE>>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
         if (L.st == S_REPLAY || lane_ready(L, tv)) {
             if (tx.count) { tc.lane_steps++; if (wave_leader()) tc.wave_steps++; }
-            lane_step2(sv, tx, a.max_depth, spp, x, y, base, L, tv, lp, acc, lc, log);
+            lane_step2<MASK>(sv, tx, a.max_depth, spp, x, y, base, L, tv, lp, acc, lc, log);
         }
     }
     flush_counters(a, lc, tc, a.count != 0);
@@ -253,6 +260,7 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_twosided(DevSceneView s
 } // namespace gd
 
 namespace gdpt {
-void launch_phases_twosided(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, void *bounce_log, hipStream_t stream);
+void launch_phases_twosided(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, unsigned material_mask, void *bounce_log, hipStream_t stream);
+void launch_phases_twosided_glass(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, void *bounce_log, hipStream_t stream);
 size_t twosided_log_bytes(unsigned blocks);
 } // namespace gdpt

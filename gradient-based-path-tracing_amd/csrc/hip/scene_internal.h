@@ -25,6 +25,7 @@ struct GdptScene {
     bool has_envmap = false;
     int scene_spp = 0;             // <sampler sampleCount> of the description (default spp)
     bool one_sided = true, lambert_only = true;
+    unsigned material_mask = 0;    // bit t = a material of type t is present
     bool has_rough = false;        // RoughPlastic / RoughDielectric present: GradPath uses the evaluator built with those lobes
     std::vector<void *> allocations;
     // cached output/work buffers for the host-pointer entry points

@@ -255,6 +255,11 @@ def test_two_sided_lane_machine_replays_offsets_exactly(G, O, scene_tmp, scene, 
     got, st = sc.render(6, G.RNG_SAMPLE)
     with G.debug_knobs(no_twosided_machine=1):
         eager, est = sc.render(6, G.RNG_SAMPLE)
+    with G.debug_knobs(full_material_switch=1):       # the kernel with every lobe vs the one built for this scene's material set
+        full, fst = sc.render(6, G.RNG_SAMPLE)
+    for k in BUFS:
+        assert rel_l2(got[k], full[k]) < 1e-12, k
+    assert (fst.rays, fst.bounces) == (st.rays, st.bounces)
     want, ost = O.OracleScene(sd.ptr, use_bvh=True).render(6, G.RNG_SAMPLE, threads=8)
     for k in BUFS:
         assert rel_l2(got[k], eager[k]) < 1e-12, k
