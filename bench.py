@@ -439,6 +439,8 @@ def _find(table, name):
 def _num_chunks(spp, pixels, lanes=256 * 2 * 256):
     """Work items per pixel of the persistent render kernel (make_chunk_plan, csrc/hip/render_kernels.hip)."""
     cap = max(1, spp * pixels // (lanes * 4))
+    if spp > cap * 56:                       # never more than 64 chunks
+        cap = (spp + 55) // 56
     rem, n = spp, 0
     while rem > 0:
         sz = 1 if rem <= 2 else min(max(1, (rem * 11 + 19) // 20), cap)

@@ -77,6 +77,7 @@ def lib():
                                                       C.POINTER(defs.GdptRenderStats), C.POINTER(defs.GdptMultiStats)]
         L.gdpt_debug_knob_set.argtypes = [C.c_char_p, C.c_double]
         L.gdpt_debug_knobs_reset.restype = None
+        L.gdpt_debug_chunk_plan.argtypes = [C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.POINTER(C.c_int32), C.c_int]
         L.gdpt_debug_get_stamps.argtypes = [C.POINTER(C.c_double)]
         L.gdpt_debug_get_stamps.restype = None
         _LIB = L
@@ -357,6 +358,15 @@ class debug_knobs:
     @staticmethod
     def reset():
         lib().gdpt_debug_knobs_reset()
+
+    @staticmethod
+    def chunk_plan(spp, film_pixels, resident_lanes=256 * 2 * 256, force_log2k=-1):
+        """Sample ranges of a pixel's work items: [begin[c], begin[c+1]) (include/gdpt_debug.h)."""
+        buf = (C.c_int32 * 80)()
+        n = lib().gdpt_debug_chunk_plan(int(spp), int(force_log2k), int(film_pixels), int(resident_lanes), buf, 80)
+        if n < 0:
+            raise GdptError("gdpt_debug_chunk_plan: capacity")
+        return list(buf)[:n + 1]
 
     @staticmethod
     def stamps():

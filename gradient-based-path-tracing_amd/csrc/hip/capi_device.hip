@@ -569,6 +569,14 @@ extern "C" {
 #endif
 const char *gdpt_build_arch(void) { return GDPT_BUILD_ARCH; }
 
+// include/gdpt_debug.h: the work-item plan of the persistent kernels, for host-side tests (no GPU needed)
+int gdpt_debug_chunk_plan(int spp, int force_log2k, long long film_pixels, long long resident_lanes, int32_t *begin, int capacity) {
+    const gdpt::ChunkPlan p = gdpt::make_chunk_plan(spp, force_log2k, film_pixels, resident_lanes);
+    if (!begin || capacity < p.n + 1) return -1;
+    for (int c = 0; c <= p.n; c++) begin[c] = p.begin[c];
+    return p.n;
+}
+
 int gdpt_scene_upload(const GdptSceneDesc *desc, int device, GdptScene **out_scene) {
     return gdpt::guarded([&]() {
         if (!out_scene) throw std::runtime_error("gdpt_scene_upload: null output");

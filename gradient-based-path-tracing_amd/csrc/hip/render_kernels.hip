@@ -199,8 +199,8 @@ unsigned persistent_blocks(const RenderLaunch &rl, long long num_items) {
 // launch on cbox 512x512x16 (tests/prof_drain.py; bounding the path length barely changed it, so it is the ITEM, not the
 // longest path). Chunks therefore shrink along the queue — each takes about 55 % of the samples still unassigned, the
 // last ones are single samples — and the queue hands out chunk 0 of every pixel, then chunk 1, ...: long items start
-// early, the tail of the launch consists of one-sample items. 16 spp -> 9,4,2,1 (as many partial records as the four
-// equal chunks before); 64 -> 36,16,7,3,1,1; 256 -> 141,64,29,13,5,2,1,1. Small bands with many samples (multi-GPU row bands) cap the chunk size so that every resident lane still sees
+// early, the tail of the launch consists of one-sample items. 16 spp on a 512^2 film -> 8,5,2,1 (as many partial
+// records as the four equal chunks before); 64 -> 32,18,8,3,2,1; 256 -> 128,71,32,14,6,3,1,1. Small bands with many samples (multi-GPU row bands) cap the chunk size so that every resident lane still sees
 // several items. One 128-byte partial record per item; gdpt_reduce_partials merges a pixel's records in chunk order,
 // so the result depends neither on which lane ran what nor on when.
 ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long lanes) {

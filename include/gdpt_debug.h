@@ -30,6 +30,7 @@
  */
 #ifndef GDPT_DEBUG_H
 #define GDPT_DEBUG_H
+#include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -41,6 +42,10 @@ int gdpt_debug_knob_set(const char *name, double value);
  * (a count), [8] publishing finished items, [9] work-queue take, [10] item -> pixel mapping, [11] unused; wall clock
  * (s_memrealtime, 100 MHz ticks): [12] first wave started, [13] first wave found the queue empty, [14] last wave ended. */
 void gdpt_debug_get_stamps(double out[16]);
+/* The work-item plan of the persistent render kernels (make_chunk_plan, csrc/hip/render_kernels.hip): chunk c of a pixel
+ * covers samples [begin[c], begin[c+1]). Returns the number of chunks (begin[] gets n + 1 entries), -1 if `capacity` is too
+ * small. force_log2k < 0: the product plan. Host only. */
+int gdpt_debug_chunk_plan(int spp, int force_log2k, long long film_pixels, long long resident_lanes, int32_t *begin, int capacity);
 /* Removes every override: the library is back on its product path. */
 void gdpt_debug_knobs_reset(void);
 

@@ -95,3 +95,25 @@ def test_no_environment_variable_reaches_the_kernels(G):
     with G.debug_knobs(log2k=2, presplit=0.5):
         pass
     G.debug_knobs.reset()
+
+
+def test_work_item_plan_invariants(G):
+    """The persistent kernels cut a pixel's samples into chunks that shrink along the queue and end in single samples
+    (so a launch drains one sample, not one long item); every sample is covered exactly once, at most 64 chunks, small
+    bands still give every resident lane several items, and 2^k equal chunks on request (the granularity tests)."""
+    import bench
+    for spp in (1, 2, 3, 4, 5, 8, 16, 17, 64, 100, 256, 1000, 4096):
+        for pixels in (64 * 64, 512 * 512, 1280 * 720, 4096 * 4096):
+            b = G.debug_knobs.chunk_plan(spp, pixels)
+            sizes = [b[i + 1] - b[i] for i in range(len(b) - 1)]
+            assert b[0] == 0 and b[-1] == spp and all(s >= 1 for s in sizes) and len(sizes) <= 64, (spp, pixels, sizes)
+            assert sizes == sorted(sizes, reverse=True), (spp, pixels, sizes)          # long items first
+            assert sizes[-1] == 1 or len(sizes) == 64, (spp, pixels, sizes)            # the queue ends in single samples
+            assert len(sizes) == bench._num_chunks(spp, pixels), (spp, pixels)          # bench.py's mirror (reduce-kernel byte model)
+    assert [b2 - b1 for b1, b2 in zip(*(lambda b: (b, b[1:]))(G.debug_knobs.chunk_plan(16, 512 * 512)))] == [8, 5, 2, 1]          # (first chunk capped at 8: at least four items per resident lane)
+    # a 64-row band of a 1024 x 1024 x 256 spp render (8 GPUs) is cut like the whole film: the plan depends on the FILM, not the band
+    assert G.debug_knobs.chunk_plan(256, 1024 * 1024) == G.debug_knobs.chunk_plan(256, 1024 * 1024)
+    small = G.debug_knobs.chunk_plan(128, 64 * 64)                                     # few pixels, many samples: capped chunk size
+    assert max(b2 - b1 for b1, b2 in zip(small, small[1:])) <= max(1, 128 * 64 * 64 // (256 * 2 * 256 * 4), (128 + 55) // 56)   # (the 64-chunk limit wins here)
+    eq = G.debug_knobs.chunk_plan(16, 512 * 512, force_log2k=2)
+    assert eq == [0, 4, 8, 12, 16]
