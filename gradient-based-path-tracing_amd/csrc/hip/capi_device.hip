@@ -421,10 +421,12 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.one_sided_materials = sc->one_sided && !sc->has_rough; rl.lambert_only = sc->lambert_only;
     rl.material_mask = sc->material_mask;
     rl.wide_stack_need = sc->wide_stack_need; rl.num_materials = sc->view.num_materials;
-    rl.scene_fits_lds = gdpt::scene_fits_lds(sc->view.num_nodes, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->bvh_depth);
+    rl.scene_fits_lds = gdpt::scene_fits_lds(sc->view.num_nodes, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->view.num_lights, sc->bvh_depth);
     // A/B overrides of the parity tests (include/gdpt_debug.h); every default below is the product path
     auto env_int = [](const char *name, int def) { return gdpt::debug_knob_int(name, def); };
     if (env_int("full_material_switch", 0)) rl.material_mask = 0x1FFu;
+    rl.no_spheres = sc->view.num_spheres == 0 && !env_int("no_plain_kernel", 0);
+    rl.const_textures = sc->view.all_textures_constant != 0;
     rl.force_eager = env_int("force_eager", 0) != 0;
     rl.thresh_a = env_int("keep_frac", -1); rl.thresh_c = env_int("search_frac", -1);
     rl.force_log2k = env_int("log2k", -1);
@@ -482,7 +484,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
         rl.wf_event = sc->wf_event; rl.wf_slots = slots;       // exactly the slots this band needs (the buffers may be larger)
     }
     rl.lds_wide = rl.scene_fits_lds && env_int("lds_wide", 1) != 0 &&
-                  gdpt::scene_fits_lds_wide(sc->view.num_nodes4, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->wide_stack_need);
+                  gdpt::scene_fits_lds_wide(sc->view.num_nodes4, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->view.num_lights, sc->wide_stack_need);
     ck(hipMemsetAsync(sc->d_counters, 0, sizeof(gdpt::RenderCounters), stream), "hipMemsetAsync(counters)");
     if (rl.stamped) ck(hipMemsetAsync(&sc->d_counters->stamps[12], 0xFF, 2 * sizeof(unsigned long long), stream), "hipMemsetAsync(stamps)");   // min slots
     if (stats) ck(hipEventRecord(sc->ev0, stream), "hipEventRecord");
@@ -531,7 +533,7 @@ void path_render_device_impl(GdptScene *sc, const GdptRenderParams *params, doub
     rl.num_cus = sc->num_cus; rl.blocks_per_cu = env_int("blocks_per_cu", 0);
     rl.lambert_only = sc->lambert_only;
     rl.scene_fits_lds = !env_int("no_lds_scene", 0) &&
-                        gdpt::scene_fits_lds_wide(sc->view.num_nodes4, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->wide_stack_need);
+                        gdpt::scene_fits_lds_wide(sc->view.num_nodes4, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->view.num_lights, sc->wide_stack_need);
     {
         size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, sc->view.cam.height, b.spp, rl.force_log2k, (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256);
         if (need > sc->partials_doubles) {

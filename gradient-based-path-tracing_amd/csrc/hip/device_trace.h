@@ -82,9 +82,11 @@ __device__ __noinline__ SphereHit sphere_hit(float o0, float o1, float o2, float
     return h;
 }
 
+// SPHERES = false: the scene holds triangles only (decided at upload), so the sphere arm is not even compiled in.
+template <bool SPHERES = true>
 GD void test_prim(const DevSceneView &sv, const DevPrim &pr, const float o[3], const float d[3], float tnear, float tfar, Hit &best) {
     unsigned gid = pr.gid;
-    if (!(gid & GDPT_SPHERE_FLAG)) {
+    if (!SPHERES || !(gid & GDPT_SPHERE_FLAG)) {
         float t, u, v;
         if (!tri_hit(o, d, tnear, tfar, pr, t, u, v)) return;
         if (best.gid >= 0 && !(t < best.t || (t == best.t && (int)gid < best.gid))) return;
@@ -186,24 +188,28 @@ GD void shading_info_sphere(const DevSphere &sp, D2 st, D3 gn, D2 &uv, Frame &fr
 
 // Builds the PathVertex of a hit. rd_spread/rd_radius: RayDifferential of the query (src/ray.h:26-40).
 // `tris` is the shading table (HBM, or the block's LDS copy); `need_uv`: some texture is not constant.
+// PLAIN (what the scene does not contain, decided at upload): bit 0 = no spheres, bit 1 = every texture constant (uv and
+// the footprint are unobservable). The code for what is absent is not compiled in.
+constexpr int kPlainNoSpheres = 1, kPlainConstTex = 2, kPlainBoth = 3;
+template <int PLAIN = 0>
 GD void make_vertex(const DevSceneView &sv, const DevTriShade *tris, bool need_uv, const Ray &ray, const Hit &h,
                     double rd_radius, double rd_spread, Vertex &v) {
     v.position = ray.org + ray.dir * (double)h.t;
     D2 st; st.x = (double)h.u; st.y = (double)h.v;
     double inv_uv_size;
     D3 gn;
-    if (h.gid < sv.num_tris) {
+    if ((PLAIN & kPlainNoSpheres) || h.gid < sv.num_tris) {
         const DevTriShade &ts = tris[h.gid];
         v.material_id = ts.material_id; v.light_id = ts.light_id;
         gn = mk(ts.gn[0], ts.gn[1], ts.gn[2]);
-        shading_info_tri(ts, st, gn, need_uv, v.uv, v.frame, inv_uv_size);
+        shading_info_tri(ts, st, gn, !(PLAIN & kPlainConstTex) && need_uv, v.uv, v.frame, inv_uv_size);
     } else {
         const DevSphere &sp = sv.spheres[h.gid - sv.num_tris];
         v.material_id = sp.material_id; v.light_id = sp.light_id;
         gn = normalize(mk((double)h.ngx, (double)h.ngy, (double)h.ngz));
         shading_info_sphere(sp, st, gn, v.uv, v.frame, inv_uv_size);
     }
-    if (need_uv && rd_spread != 0.0) {
+    if (!(PLAIN & kPlainConstTex) && need_uv && rd_spread != 0.0) {
         D3 dlt = ray.org - v.position;
         double dist = sqrt(dot(dlt, dlt));
         double ray_radius = rd_radius + rd_spread * dist;
@@ -216,11 +222,13 @@ GD void make_vertex(const DevSceneView &sv, const DevTriShade *tris, bool need_u
 }
 
 // emission(), src/intersection.cpp:87-98 + src/lights/diffuse_area_light.inl:15-20
-GD D3 emission(const DevSceneView &sv, const Vertex &v, D3 view_dir) {
+// `lights`: the intensity table (3 per area light) — HBM, or the block's LDS copy (TraceCtx::lights)
+GD D3 emission(const double *lights, const Vertex &v, D3 view_dir) {
     if (dot(v.gn, view_dir) <= 0) return splat(0);
-    const double *L = sv.light_intensity + 3 * v.light_id;
+    const double *L = lights + 3 * v.light_id;
     return mk(L[0], L[1], L[2]);
 }
+GD D3 emission(const DevSceneView &sv, const Vertex &v, D3 view_dir) { return emission(sv.light_intensity, v, view_dir); }
 
 // ---- camera, src/camera.cpp:23-47 + src/filters/*.inl ----------------------------------------------
 GD D2 filter_sample(int type, double param, double rx, double ry) {

@@ -154,6 +154,7 @@ struct TraceCtx {
     const DevPrim *prims;
     const DevTriShade *tris;
     const GdptMaterial *materials;
+    const double *lights;    // area-light intensities
     int *stack;
     int stride;
     bool count;       // wave-uniform: count BVH nodes / primitives (bench roofline accounting)
@@ -191,7 +192,7 @@ GD void visit_wide(const DevBvh4Node &n, const float oi[3], const float inv[3], 
 
 // A leaf holds 1..4 primitive records. All of them are fetched before the first test (indices clamped to the leaf, so
 // short leaves re-read their last record): the leaf then costs one memory latency instead of one per primitive.
-template <bool FLAT>
+template <bool FLAT, bool SPHERES = true>
 GD void test_leaf(const DevSceneView &sv, const TraceCtx &tx, int cur, const float o[3], const float d[3], float tnear, float tfar,
                   Hit &best, TraceCounters &tc) {
     const unsigned packed = ~(unsigned)cur;
@@ -203,11 +204,11 @@ GD void test_leaf(const DevSceneView &sv, const TraceCtx &tx, int cur, const flo
     if (tx.count) { tc.prims += last + 1u; if (wave_leader()) tc.leaf_trips++; }
     // FLAT (scenes walked from HBM, incoherent rays): four branch-free triangle tests. Otherwise (small LDS-resident
     // scenes, where whole waves miss a triangle together) the early-outs of tri_hit pay.
-    if (!FLAT || ((p0.gid | p1.gid | p2.gid | p3.gid) & GDPT_SPHERE_FLAG)) {     // (a sphere in the leaf: general test)
-        test_prim(sv, p0, o, d, tnear, tfar, best);
-        if (last >= 1u) test_prim(sv, p1, o, d, tnear, tfar, best);
-        if (last >= 2u) test_prim(sv, p2, o, d, tnear, tfar, best);
-        if (last >= 3u) test_prim(sv, p3, o, d, tnear, tfar, best);
+    if (!FLAT || (SPHERES && ((p0.gid | p1.gid | p2.gid | p3.gid) & GDPT_SPHERE_FLAG))) {     // (a sphere in the leaf: general test)
+        test_prim<SPHERES>(sv, p0, o, d, tnear, tfar, best);
+        if (last >= 1u) test_prim<SPHERES>(sv, p1, o, d, tnear, tfar, best);
+        if (last >= 2u) test_prim<SPHERES>(sv, p2, o, d, tnear, tfar, best);
+        if (last >= 3u) test_prim<SPHERES>(sv, p3, o, d, tnear, tfar, best);
     } else {
         test_tri_flat(p0, o, d, tnear, tfar, true, best);
         test_tri_flat(p1, o, d, tnear, tfar, last >= 1u, best);
@@ -259,7 +260,7 @@ GD void trav_node(const TraceCtx &tx, const float oi[3], const float inv[3], flo
     }
 }
 // Compile-time traversal configuration of a kernel: loop order, tree form, leaf test style.
-template <bool WW_, bool WIDE_, bool FLAT_> struct TraceCfg { static constexpr bool WW = WW_, WIDE = WIDE_, FLAT = FLAT_; };
+template <bool WW_, bool WIDE_, bool FLAT_, bool SPHERES_ = true> struct TraceCfg { static constexpr bool WW = WW_, WIDE = WIDE_, FLAT = FLAT_, SPHERES = SPHERES_; };
 using TraceHbm = TraceCfg<true, true, true>;       // scenes walked from HBM
 
 // Called by the lanes whose ray is unfinished (tv.cur != kTravDone); the others of the wave sit it out.
@@ -293,7 +294,7 @@ GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, flo
                 }
             }
             if (cur < 0 && cur != kTravDone) {
-                test_leaf<TC::FLAT>(sv, tx, cur, o, d, tnear, tfar, best, tc);
+                test_leaf<TC::FLAT, TC::SPHERES>(sv, tx, cur, o, d, tnear, tfar, best, tc);
                 trav_pop(tx, cur, sp);
                 if (any_hit && best.gid >= 0) cur = kTravDone;
             }
@@ -301,7 +302,7 @@ GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, flo
             if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
             trav_node<TC::WIDE>(tx, oi, inv, tnear, best.t, cur, sp);
         } else if (cur != kTravDone) {
-            test_leaf<TC::FLAT>(sv, tx, cur, o, d, tnear, tfar, best, tc);
+            test_leaf<TC::FLAT, TC::SPHERES>(sv, tx, cur, o, d, tnear, tfar, best, tc);
             trav_pop(tx, cur, sp);
             if (any_hit && best.gid >= 0) cur = kTravDone;
         }
@@ -343,14 +344,15 @@ GD bool mat_sample(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, 
     return bsdf_sample<ROUGH, TWOSIDED, MASK>(sv, tx.materials[v.material_id], in, v, ruv, rw, s);
 }
 // eval (f*|cos|) and solid-angle pdf together
-template <bool LAMBERT, bool ROUGH = false, bool TWOSIDED = false, unsigned MASK = kAllMaterials>
+template <bool LAMBERT, bool ROUGH = false, bool TWOSIDED = false, unsigned MASK = kAllMaterials, int PLAIN = 0>
 GD void mat_eval_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D3 out, D3 &f, double &pdf) {
     if (LAMBERT) {
         // src/materials/lambertian.inl:1-33 — eval and pdf share the clamped cosine
         if (below(v, in) || below(v, out)) { f = splat(0); pdf = 0; return; }
         Frame fr = oriented_frame(v, in);
         double c = fmax(dot(fr.n, out), 0.0);
-        f = c * tex3(sv, tx.materials[v.material_id].tex[0], v) / kPi;
+        const GdptTexture &refl = tx.materials[v.material_id].tex[0];
+        f = c * ((PLAIN & kPlainConstTex) ? mk(refl.v0[0], refl.v0[1], refl.v0[2]) : tex3(sv, refl, v)) / kPi;
         pdf = c / kPi;
         return;
     }
@@ -415,7 +417,11 @@ struct Lane {
 
 // SERIAL_RNG: one PCG stream runs through consecutive samples (TILE scheme); otherwise each sample owns stream
 // `base + s` (SAMPLE scheme) and its sub-pixel / bounce-1 numbers are re-derived from it when an offset needs them.
-template <bool LAMBERT, bool SERIAL_RNG, class ACC, class STAMPS = Stamps<false>>
+// PLAIN: device_trace.h (kPlainNoSpheres | kPlainConstTex): sphere / texture code is not compiled in.
+// (Tried: keeping the sample's sub-pixel and bounce-1 numbers in 10 VGPRs for the offsets instead of re-deriving them from
+// the sample's stream, for the kernels with register headroom: the compiler already shares the derivation between the
+// two places that need it — 36 of 2883 vector instructions less, no change in run time.)
+template <bool LAMBERT, bool SERIAL_RNG, class ACC, class STAMPS = Stamps<false>, int PLAIN = 0>
 GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, double spp, int x, int y, unsigned long long base,
                   Lane &L, Trav &tv, LanePriv &lp, ACC &acc, LaneCounters &lc, TraceCounters &tc, STAMPS *stp = nullptr) {
     STAMPS none; STAMPS &stamps = stp ? *stp : none;
@@ -433,7 +439,7 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
     if (tracing) {
         lc.rays++;
         hit = tv.best.gid >= 0;
-        if (hit) make_vertex(sv, tx.tris, tx.need_uv, ray, tv.best, 0.0, (st0 == S_BOUNCE) ? 0.0 : 0.25 / (double)max(w, h), nv);   // src/ray.h:33-35, :564
+        if (hit) make_vertex<PLAIN>(sv, tx.tris, tx.need_uv, ray, tv.best, 0.0, (st0 == S_BOUNCE) ? 0.0 : 0.25 / (double)max(w, h), nv);   // src/ray.h:33-35, :564
     }
     stamps.mark(SEG_VERTEX);
     // ---------------- consume the hit ----------------
@@ -446,7 +452,7 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
             L.contrib = splat(1.0); L.throughput = splat(1.0);
             L.prob = 1.0;
             D3 rad0 = splat(0);
-            if (nv.light_id >= 0) { D3 Le = emission(sv, nv, -ray.dir); rad0 = Le; L.contrib = Le; }   // :490-493
+            if (nv.light_id >= 0) { D3 Le = emission(tx.lights, nv, -ray.dir); rad0 = Le; L.contrib = Le; }   // :490-493
             lp.set_radiance(rad0); lp.set_p2_1(1.0);
             L.num_vertices = 3;
             if (!loop_allows(max_depth, 3)) { L.kc = C_NO_LOOP << 2; act = ACT_OFFSETS; } else act = ACT_BOUNCE;
@@ -460,7 +466,7 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
         L.contrib = L.contrib * f * G; L.prob *= p2;                                // :769-770
         if (first) lp.set_p2_1(p2);
         if (hit && nv.light_id >= 0) {                                              // :971-980
-            D3 Le = emission(sv, nv, -ray.dir);
+            D3 Le = emission(tx.lights, nv, -ray.dir);
             D3 C2 = (G * f) * Le;
             L.contrib = L.contrib * Le;
             lp.set_radiance(lp.radiance() + L.throughput * (C2 / p2));
@@ -512,7 +518,7 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
         }
         const D3 dir_view = -ray.dir;
         sampled = mat_sample<LAMBERT>(sv, tx, nv, dir_view, ruv, rw, bs);
-        if (sampled) mat_eval_pdf<LAMBERT>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
+        if (sampled) mat_eval_pdf<LAMBERT, false, false, kAllMaterials, PLAIN>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
     }
     stamps.mark(SEG_BSDF);
     if (st0 == S_OFFSET) {
@@ -520,7 +526,7 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
         D3 cX = splat(0);
         double wgt = 1.0;
         if (off_valid) {
-            D3 c0 = (nv.light_id >= 0) ? emission(sv, nv, -ray.dir) : splat(1.0);   // :496-508
+            D3 c0 = (nv.light_id >= 0) ? emission(tx.lights, nv, -ray.dir) : splat(1.0);   // :496-508
             double jac = 1.0;
             bool alive = true;
             if (off_resample) {
@@ -665,13 +671,20 @@ GD TraceCtx setup_trace(const DevSceneView &sv, unsigned char *s_scene, int *s_s
         for (int i = tid; i < pw; i += nthreads) dst[nw + i] = s1[i];
         for (int i = tid; i < tw; i += nthreads) dst[nw + pw + i] = s2[i];
         for (int i = tid; i < mw; i += nthreads) dst[nw + pw + tw + i] = s3[i];
+        // the light table too: a global load in the loop makes its s_waitcnt vmcnt also wait for the acknowledgement of
+        // every partial-sum store issued before it (one in-order counter for loads and stores on gfx9)
+        const int l0 = (nw + pw + tw + mw + 1) & ~1, lw = sv.num_lights * 6;
+        const unsigned *s4 = (const unsigned *)sv.light_intensity;
+        for (int i = tid; i < lw; i += nthreads) dst[l0 + i] = s4[i];
         __syncthreads();
+        tx.lights = (const double *)(s_scene + (size_t)l0 * 4);
         tx.nodes = (const DevBvhNode *)s_scene; tx.nodes4 = (const DevBvh4Node *)s_scene;
         tx.prims = (const DevPrim *)(s_scene + (size_t)nw * 4);
         tx.tris = (const DevTriShade *)(s_scene + (size_t)(nw + pw) * 4);
         tx.materials = (const GdptMaterial *)(s_scene + (size_t)(nw + pw + tw) * 4);
     } else {
         tx.nodes = sv.nodes; tx.nodes4 = sv.nodes4; tx.prims = sv.prims; tx.tris = sv.tris; tx.materials = sv.materials;
+        tx.lights = sv.light_intensity;
     }
     return tx;
 }
@@ -687,12 +700,13 @@ GD TraceCtx setup_trace(const DevSceneView &sv, unsigned char *s_scene, int *s_s
 // items still in flight when the queue runs dry are single samples: the kernel's drain is one short sample long
 // instead of one long item (measured: 0.44 ms -> see DESIGN.md 4.1). One 32-bit division per started item for the
 // chunk, one for the tile row. Returns false for an empty slot.
-GD bool item_to_pixel(const KernelArgs &a, int W, unsigned item, int &x, int &y, int &s0, int &s1) {
+// `chunks`: a.chunk_begin, or the block's LDS copy of it (lane machine: no global load in the loop, see setup_trace).
+GD bool item_to_pixel(const KernelArgs &a, int W, unsigned item, int &x, int &y, int &s0, int &s1, const int *chunks) {
     const unsigned c = item / (unsigned)a.num_slots, pt = item - c * (unsigned)a.num_slots;
     const unsigned pin = pt & 255u, tile = pt >> 8;
     const unsigned ty = tile / (unsigned)a.tiles_x, tx = tile - ty * (unsigned)a.tiles_x;
     x = (int)(tx * 16u + (pin & 15u)); y = a.row_begin + (int)(ty * 16u + (pin >> 4));
-    s0 = a.chunk_begin[c]; s1 = a.chunk_begin[c + 1];
+    s0 = chunks[c]; s1 = chunks[c + 1];
     return x < W && y < a.row_end;
 }
 
@@ -739,7 +753,7 @@ struct WaveQueue {
 // that finishes early picks up the next item instead of idling behind the longest path of its wave. Per-item sums go
 // to `partials` ([15][items], one writer per slot) and are merged per pixel in chunk order by gdpt_reduce_partials,
 // so the result does not depend on which lane processed what, or when.
-template <bool LAMBERT, bool LDS_SCENE, bool WIDE, bool WW, bool STAMPED = false>
+template <bool LAMBERT, bool LDS_SCENE, bool WIDE, bool WW, bool STAMPED = false, int PLAIN = 0>
 __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv, KernelArgs a) {
     // LDS-resident scenes: fixed 12-slot stack + the scene copy. Scenes walked from HBM: dynamic LDS = a.stack_levels stack
     // slots per lane (the tree's own bound, not the builder's maximum of 32).
@@ -747,10 +761,13 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
     __shared__ __attribute__((aligned(16))) unsigned char s_scene[LDS_SCENE ? kLdsSceneBytes : 16];
     __shared__ double s_acc[15 * kBlock];
     __shared__ double s_priv[kPrivDoubles * kBlock];
+    __shared__ int s_chunks[66];
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     int *s_stack = LDS_SCENE ? s_stack_fixed : (int *)s_dyn;
     const int tid = threadIdx.x;
+    if (tid <= a.num_chunks && tid < 66) s_chunks[tid] = a.chunk_begin[tid];       // LDS copy of the chunk table (item_to_pixel)
     TraceCtx tx = setup_trace<LDS_SCENE, WIDE>(sv, s_scene, s_stack, tid, kBlock, a.count != 0);
+    if (!LDS_SCENE) __syncthreads();                                                // (for LDS scenes setup_trace ends with the barrier)
     const int W = sv.cam.width;
     const double spp = (double)a.spp;
     AccLds acc; acc.slot = s_acc + tid; acc.stride = kBlock;
@@ -792,7 +809,7 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
         if (got_item >= 0) {
             my_item = got_item;
             int s0, s1;
-            const bool inside = item_to_pixel(a, W, (unsigned)my_item, x, y, s0, s1);
+            const bool inside = item_to_pixel(a, W, (unsigned)my_item, x, y, s0, s1, s_chunks);
             base = ((unsigned long long)y * W + x) * (unsigned long long)a.spp;
             L.s = s0; L.s_end = s1;
             L.st = (inside && s0 < s1) ? S_START : S_DONE;
@@ -800,12 +817,12 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
         stamps.mark(SEG_ITEM);
         if (!__any(L.st != S_DONE)) { if (wq.exhausted) break; else continue; }
         stamps.mark(SEG_QUEUE);
-        trace_pending<TraceCfg<WW, WIDE, !LDS_SCENE>>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
+        trace_pending<TraceCfg<WW, WIDE, !LDS_SCENE, !(PLAIN & kPlainNoSpheres)>>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
         stamps.mark(SEG_TRACE);
         stamps.tick(SEG_STEPS);
         if (lane_ready(L, tv)) {
             if (tx.count) { tc.lane_steps++; if (wave_leader()) tc.wave_steps++; }
-            lane_step<LAMBERT, false, AccLds, Stamps<STAMPED>>(sv, tx, a.max_depth, spp, x, y, base, L, tv, lp, acc, lc, tc, &stamps);
+            lane_step<LAMBERT, false, AccLds, Stamps<STAMPED>, PLAIN>(sv, tx, a.max_depth, spp, x, y, base, L, tv, lp, acc, lc, tc, &stamps);
         }
     }
     flush_counters(a, lc, tc, a.count != 0);
@@ -826,7 +843,7 @@ __global__ __launch_bounds__(256) void gdpt_reduce_partials(KernelArgs a, int W)
     const int j = (int)(t & 15);
     if (idx >= nslots || j == 15) return;
     int x, y, s0, s1;
-    if (!item_to_pixel(a, W, (unsigned)idx, x, y, s0, s1)) return;
+    if (!item_to_pixel(a, W, (unsigned)idx, x, y, s0, s1, a.chunk_begin)) return;
     const double *src = a.partials + (size_t)idx * 16 + j;
     double v = 0;
     for (int c = 0; c < a.num_chunks; c++) v += src[(size_t)c * (size_t)nslots * 16];
@@ -1054,7 +1071,8 @@ __global__ __launch_bounds__(64) void gdpt_render_tile_stream_eager(DevSceneView
 namespace gdpt {
 // host launchers, one translation unit per kernel family (parallel compilation)
 void launch_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lds_wide, hipStream_t stream);
-void launch_phases_lambert_stamped(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, hipStream_t stream);   // diagnostic build
+void launch_phases_lambert_plain(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool const_tex, hipStream_t stream);   // triangles only (and constant textures)
+void launch_phases_lambert_stamped(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool plain, hipStream_t stream);   // diagnostic build
 void launch_reduce_partials(const DevSceneView &sv, const gd::KernelArgs &a, hipStream_t stream);
 void launch_phases_general(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lds_wide, hipStream_t stream);
 void launch_phases_twosided(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, unsigned material_mask, void *bounce_log, hipStream_t stream);

@@ -48,12 +48,13 @@ struct RenderLaunch {
     unsigned *wf_host;             // pinned, 1 word (live-count read-back)
     hipEvent_t wf_event;
     int wf_slots;
+    bool no_spheres, const_textures;   // triangles only / every texture constant: kernels built without sphere / texture code
     bool stamped;                  // diagnostic build with in-kernel cycle stamps (test-only knob "stamps")
     double *partials;              // device, >= 15 * W * rows * 8 doubles (work-item partial sums)
     unsigned long long *queue_head;// device, work-queue head
 };
-bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_materials, int bvh_depth);
-bool scene_fits_lds_wide(int num_nodes4, int num_prims, int num_tris, int num_materials, int wide_stack_need);
+bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_materials, int num_lights, int bvh_depth);
+bool scene_fits_lds_wide(int num_nodes4, int num_prims, int num_tris, int num_materials, int num_lights, int wide_stack_need);
 
 // Doubles the `partials` buffer must hold for a band of `pixels` pixels at `spp`.
 size_t twosided_log_bytes(unsigned blocks);

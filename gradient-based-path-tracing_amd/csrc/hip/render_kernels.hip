@@ -129,7 +129,8 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
             } else if (rl.two_sided_machine) {
                 if (!rl.bounce_log || rl.bounce_log_bytes < twosided_log_bytes(blocks)) throw std::runtime_error("launch_render: bounce log missing");
                 launch_phases_twosided(sv, a, grid, rl.scene_fits_lds && rl.lds_wide, rl.material_mask, rl.bounce_log, stream);
-            } else if (rl.lambert_only && rl.stamped && (!rl.scene_fits_lds || rl.lds_wide)) launch_phases_lambert_stamped(sv, a, grid, rl.scene_fits_lds, stream);
+            } else if (rl.lambert_only && rl.stamped && (!rl.scene_fits_lds || rl.lds_wide)) launch_phases_lambert_stamped(sv, a, grid, rl.scene_fits_lds, rl.no_spheres && rl.const_textures, stream);
+            else if (rl.lambert_only && rl.no_spheres && (!rl.scene_fits_lds || rl.lds_wide)) launch_phases_lambert_plain(sv, a, grid, rl.scene_fits_lds, rl.const_textures, stream);
             else if (rl.lambert_only) launch_phases_lambert(sv, a, grid, rl.scene_fits_lds, rl.lds_wide, stream);
             else launch_phases_general(sv, a, grid, rl.scene_fits_lds, rl.lds_wide, stream);
             launch_reduce_partials(sv, a, stream);
@@ -238,15 +239,15 @@ size_t render_partials_doubles(int width, int rows, int film_height, int spp, in
     return (size_t)16 * (size_t)(tiles * 256) * (size_t)make_chunk_plan(spp, force_log2k, (long long)width * film_height, lanes).n;
 }
 
-bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_materials, int bvh_depth) {
+bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_materials, int num_lights, int bvh_depth) {
     size_t bytes = (size_t)num_nodes * sizeof(DevBvhNode) + (size_t)num_prims * sizeof(DevPrim) +
-                   (size_t)num_tris * sizeof(DevTriShade) + (size_t)num_materials * sizeof(GdptMaterial);
+                   (size_t)num_tris * sizeof(DevTriShade) + (size_t)num_materials * sizeof(GdptMaterial) + 8 + (size_t)num_lights * 24;
     return bytes <= (size_t)gd::kLdsSceneBytes && bvh_depth <= gd::kLdsSceneLevels && num_nodes > 0;
 }
 
-bool scene_fits_lds_wide(int num_nodes4, int num_prims, int num_tris, int num_materials, int wide_stack_need) {
+bool scene_fits_lds_wide(int num_nodes4, int num_prims, int num_tris, int num_materials, int num_lights, int wide_stack_need) {
     size_t bytes = (size_t)num_nodes4 * sizeof(DevBvh4Node) + (size_t)num_prims * sizeof(DevPrim) +
-                   (size_t)num_tris * sizeof(DevTriShade) + (size_t)num_materials * sizeof(GdptMaterial);
+                   (size_t)num_tris * sizeof(DevTriShade) + (size_t)num_materials * sizeof(GdptMaterial) + 8 + (size_t)num_lights * 24;
     return bytes <= (size_t)gd::kLdsSceneBytes && wide_stack_need <= gd::kLdsSceneLevels && num_nodes4 > 0;
 }
 

@@ -576,7 +576,7 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_path_persistent(DevSceneView s
         if (got_item >= 0) {
             my_item = got_item;
             int s0, s1;
-            const bool inside = item_to_pixel(a, W, (unsigned)my_item, x, y, s0, s1);
+            const bool inside = item_to_pixel(a, W, (unsigned)my_item, x, y, s0, s1, a.chunk_begin);
             base = ((unsigned long long)y * W + x) * (unsigned long long)a.spp;
             L.s = s0; L.s_end = s1;
             L.st = (inside && s0 < s1) ? P_START : P_DONE;
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void gdpt_path_reduce(KernelArgs a, int W) {
     const int j = (int)(t & 3);
     if (idx >= nslots || j == 3) return;
     int x, y, s0, s1;
-    if (!item_to_pixel(a, W, (unsigned)idx, x, y, s0, s1)) return;
+    if (!item_to_pixel(a, W, (unsigned)idx, x, y, s0, s1, a.chunk_begin)) return;
     const double *src = a.partials + (size_t)idx * 4 + j;
     double v = 0;
     for (int c = 0; c < a.num_chunks; c++) v += src[(size_t)c * (size_t)nslots * 4];

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_twosided(DevSceneView s
         if (got_item >= 0) {
             my_item = got_item;
             int s0, s1;
-            const bool inside = item_to_pixel(a, W, (unsigned)my_item, x, y, s0, s1);
+            const bool inside = item_to_pixel(a, W, (unsigned)my_item, x, y, s0, s1, a.chunk_begin);
             base = ((unsigned long long)y * W + x) * (unsigned long long)a.spp;
             L.s = s0; L.s_end = s1;
             L.st = (inside && s0 < s1) ? S_START : S_DONE;

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void gdpt_wf_step(DevSceneView sv, KernelAr
             if (idle && mine < a.num_items) {
                 my_item = mine;
                 int s0, s1;
-                const bool inside = item_to_pixel(a, W, (unsigned)my_item, x, y, s0, s1);
+                const bool inside = item_to_pixel(a, W, (unsigned)my_item, x, y, s0, s1, a.chunk_begin);
                 L.s = s0; L.s_end = s1;
                 L.st = (inside && s0 < s1) ? S_START : S_DONE;
                 L.kc = 0; L.num_vertices = 0; L.mats = 0xFFFFFF; L.rng_state = 0; L.rng_inc = 1;

@@ -1,0 +1,23 @@
+"""Manual A/B (not collected by pytest), same process and box: one debug knob off/on, several scenes.
+   python tests/ab_knob.py <knob> [value_on] — prints the best of 5 render times per setting and whether the five buffers are bit-identical."""
+import os, sys, tempfile
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import gdpt_amd as G
+from helpers import scene_variant
+knob = sys.argv[1]; on = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+tmp = tempfile.mkdtemp()
+cases = [("cbox 512x512x16", "cbox/cbox_gdpt.xml", 512, 512, None, 16), ("cbox 512x512x256", "cbox/cbox_gdpt.xml", 512, 512, None, 256),
+         ("sponza 1280x720x16", "sponza/sponza.xml", 1280, 720, None, 16), ("disney_diffuse 512x512x16", "disney_bsdf_test/disney_diffuse.xml", 512, 512, "gradpath", 16)]
+for name, rel, w, h, integ, spp in cases:
+    sc = G.Scene(G.parse_scene(scene_variant(tmp, rel, width=w, height=h, integrator=integ)))
+    res, bufs = {}, {}
+    for rep in range(5):
+        for mode in (0, on):
+            with G.debug_knobs(**{knob: mode}):
+                b, st = sc.render(spp, G.RNG_SAMPLE)
+            res.setdefault(mode, []).append(st.render_ms); bufs[mode] = b
+    same = all(np.array_equal(bufs[0][k], bufs[on][k], equal_nan=True) for k in bufs[0])
+    print(f"{name}: {knob}=0 {min(res[0]):.3f} ms ({st.samples / min(res[0]) / 1e3:.1f} Msamples/s) | {knob}={on} {min(res[on]):.3f} ms "
+          f"({st.samples / min(res[on]) / 1e3:.1f} Msamples/s) | buffers identical: {same}", flush=True)
