@@ -233,10 +233,20 @@ GD void trav_init(const DevSceneView &sv, Trav &tv, double tfar) {
 GD void trav_pop(const TraceCtx &tx, int &cur, int &sp) {
     if (sp > 0) { sp--; cur = tx.stack[sp * tx.stride]; } else cur = kTravDone;
 }
-template <bool WIDE>
+template <bool WIDE, bool HBM = false>
 GD void trav_node(const TraceCtx &tx, const float oi[3], const float inv[3], float tnear, float tb, int &cur, int &sp) {
     if (WIDE) {
         WideVisit w;
+#ifdef GDPT_EXTRA_LOOKUPS     // experiment: seven more L1 lookups per node visit (hits), results unchanged
+        if (HBM) {
+            const char *np = (const char *)&tx.nodes4[cur];
+            unsigned d0, d1, d2, d3, d4, d5, d6;
+            asm volatile("global_load_dword %0, %7, off\n global_load_dword %1, %7, off offset:16\n global_load_dword %2, %7, off offset:32\n"
+                         "global_load_dword %3, %7, off offset:48\n global_load_dword %4, %7, off offset:64\n global_load_dword %5, %7, off offset:80\n"
+                         "global_load_dword %6, %7, off offset:96\n s_waitcnt vmcnt(0)"
+                         : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6) : "v"(np) : "memory");
+        }
+#endif
         visit_wide(tx.nodes4[cur], oi, inv, tnear, tb, w);
         if (w.key[0] != kMissKey) {
             if (w.key[3] != kMissKey) { tx.stack[sp * tx.stride] = w.ch[3]; sp++; }
@@ -290,7 +300,7 @@ GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, flo
                 if (__popcll(__ballot(searching)) <= few) break;
                 if (searching) {
                     if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
-                    trav_node<TC::WIDE>(tx, oi, inv, tnear, best.t, cur, sp);
+                    trav_node<TC::WIDE, TC::FLAT>(tx, oi, inv, tnear, best.t, cur, sp);
                 }
             }
             if (cur < 0 && cur != kTravDone) {
@@ -300,7 +310,7 @@ GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, flo
             }
         } else if (cur >= 0) {
             if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
-            trav_node<TC::WIDE>(tx, oi, inv, tnear, best.t, cur, sp);
+            trav_node<TC::WIDE, TC::FLAT>(tx, oi, inv, tnear, best.t, cur, sp);
         } else if (cur != kTravDone) {
             test_leaf<TC::FLAT, TC::SPHERES>(sv, tx, cur, o, d, tnear, tfar, best, tc);
             trav_pop(tx, cur, sp);
@@ -688,10 +698,12 @@ GD TraceCtx setup_trace(const DevSceneView &sv, unsigned char *s_scene, int *s_s
     }
     return tx;
 }
-// (Tried: a copy of the material table in LDS behind the stack for scenes walked from HBM — every texture / parameter read
-// of every BSDF call goes through that table. Because the choice is made at run time the table pointer becomes a generic
-// pointer and every read a flat_load waiting on both counters: the Disney scenes ran 5-10 % slower, so the table stays in
-// HBM / L1 for them; only the stack is sized from the tree's own bound.)
+// (Tried twice: a copy of the material table in LDS behind the stack for scenes walked from HBM — every texture / parameter
+// read of every BSDF call goes through that table. Chosen at run time the table pointer becomes a generic pointer and every
+// read a flat_load waiting on both counters: 5-10 % slower. Chosen at compile time (a kernel template flag, ds_read
+// confirmed in the ISA; only ~40 of the glass kernel's 420 global loads are table reads): still 2 % slower than leaving
+// the table in HBM / L1 on disney_glass — and 25 % slower when a fixed 12 KB array on top of a deep tree's stack leaves room
+// for one block per CU only. The table stays in HBM / L1; only the stack is sized from the tree's own bound.)
 
 // Work items of the persistent kernels: item = chunk * num_slots + slot, slot = tile * 256 + pixel_in_tile, tiles = the
 // reference's 16x16 tiles of the band in row-major order (ragged edge tiles keep all 256 slots; their outside pixels

@@ -1,5 +1,5 @@
 """Manual A/B (not collected by pytest), same process and box: one debug knob off/on, several scenes.
-   python tests/ab_knob.py <knob> [value_on] — prints the best of 5 render times per setting and whether the five buffers are bit-identical."""
+   python tests/ab_knob.py <knob> [value_on [case,case..]] — prints the best of 5 render times per setting and whether the five buffers are bit-identical."""
 import os, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,11 @@ from helpers import scene_variant
 knob = sys.argv[1]; on = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 tmp = tempfile.mkdtemp()
 cases = [("cbox 512x512x16", "cbox/cbox_gdpt.xml", 512, 512, None, 16), ("cbox 512x512x256", "cbox/cbox_gdpt.xml", 512, 512, None, 256),
-         ("sponza 1280x720x16", "sponza/sponza.xml", 1280, 720, None, 16), ("disney_diffuse 512x512x16", "disney_bsdf_test/disney_diffuse.xml", 512, 512, "gradpath", 16)]
+         ("sponza 1280x720x16", "sponza/sponza.xml", 1280, 720, None, 16), ("disney_diffuse 512x512x16", "disney_bsdf_test/disney_diffuse.xml", 512, 512, "gradpath", 16),
+         ("disney_metal 512x512x16", "disney_bsdf_test/disney_metal.xml", 512, 512, "gradpath", 16),
+         ("disney_glass 512x512x16", "disney_bsdf_test/disney_glass.xml", 512, 512, "gradpath", 16), ("disney_bsdf 512x512x16", "disney_bsdf_test/disney_bsdf.xml", 512, 512, "gradpath", 16)]
+if len(sys.argv) > 3:
+    cases = [c for c in cases if any(c[0].startswith(w) for w in sys.argv[3].split(","))]
 for name, rel, w, h, integ, spp in cases:
     sc = G.Scene(G.parse_scene(scene_variant(tmp, rel, width=w, height=h, integrator=integ)))
     res, bufs = {}, {}
