@@ -427,6 +427,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     if (env_int("full_material_switch", 0)) rl.material_mask = 0x1FFu;
     rl.no_spheres = sc->view.num_spheres == 0 && !env_int("no_plain_kernel", 0);
     rl.const_textures = sc->view.all_textures_constant != 0;
+    rl.replay_per_step = env_int("replay_per_step", 0);
     rl.force_eager = env_int("force_eager", 0) != 0;
     rl.thresh_a = env_int("keep_frac", -1); rl.thresh_c = env_int("search_frac", -1);
     rl.force_log2k = env_int("log2k", -1);

@@ -69,6 +69,7 @@ struct KernelArgs {
     int thresh_a, thresh_c;
     int count;
     int stack_levels;                  // scenes walked from HBM: traversal-stack slots per lane in dynamic LDS (= the tree's bound)
+    int replay_per_step;               // two-sided lane machine: replay iterations of an offset per wave step (>= 1)
     int num_chunks;                    // work items per pixel: chunk c covers samples [chunk_begin[c], chunk_begin[c+1])
     long long num_slots;               // pixel slots of the band: tiles * 256 (ragged edge tiles keep all 256)
     long long num_items;               // num_slots * num_chunks (< 2^32); item = chunk * num_slots + slot ("tier-major")
@@ -148,7 +149,7 @@ GD void acc_no_offsets(ACC &a, D3 radiance, D3 contrib, double prob, double spp,
 // ------------------------------------------------------------------------------------------------
 // scene memory view: BVH nodes / primitive records from HBM or from the block's LDS copy
 // ------------------------------------------------------------------------------------------------
-struct TraceCtx {
+struct TraceCtx {      // (every field is set by setup_trace or, for the wavefront kernels, by hand: keep the two in step)
     const DevBvhNode *nodes;
     const DevBvh4Node *nodes4;
     const DevPrim *prims;

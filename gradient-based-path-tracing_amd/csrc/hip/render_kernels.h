@@ -48,6 +48,7 @@ struct RenderLaunch {
     unsigned *wf_host;             // pinned, 1 word (live-count read-back)
     hipEvent_t wf_event;
     int wf_slots;
+    int replay_per_step;           // two-sided lane machine (render_twosided.h), 0 = default
     bool no_spheres, const_textures;   // triangles only / every texture constant: kernels built without sphere / texture code
     bool stamped;                  // diagnostic build with in-kernel cycle stamps (test-only knob "stamps")
     double *partials;              // device, >= 15 * W * rows * 8 doubles (work-item partial sums)

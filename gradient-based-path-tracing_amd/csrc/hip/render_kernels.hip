@@ -117,6 +117,7 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
             if (a.num_items >= (1LL << 32)) throw std::runtime_error("launch_render: image band too large for the 32-bit work queue");
             // scenes walked from HBM: stack slots = the tree's own bound (host-verified at upload)
             a.stack_levels = rl.wide_stack_need > 0 ? rl.wide_stack_need : GDPT_BVH_MAX_DEPTH;
+            a.replay_per_step = rl.replay_per_step >= 1 ? rl.replay_per_step : 4;       // render_twosided.h: kReplayPerStep
             if (a.stack_levels > GDPT_BVH_MAX_DEPTH) throw std::runtime_error("launch_render: traversal stack bound exceeds the builder's maximum");
             a.partials = rl.partials; a.queue_head = rl.queue_head;
             if (!a.partials || !a.queue_head) throw std::runtime_error("launch_render: work-queue buffers missing");

@@ -20,6 +20,7 @@ namespace gd {
 
 constexpr int S_REPLAY = 5;            // after S_DONE = 4: an offset re-sampling its primary vertex, no pending ray
 constexpr int kLogCap = 1024;
+constexpr int kReplayPerStep = 4;       // replay iterations of an offset per wave step (KernelArgs::replay_per_step; test knob)
 struct BounceLog { double p2; int mat; int pad; };   // p2 < 0: the iteration broke at pdf <= 0 (before any update); log[it * kBlock] = iteration `it` of this lane
 
 // LDS slot of a lane (doubles, stride kBlock): 0..2 radiance, 3 eta_scale, 4..7 filter cache
@@ -40,7 +41,7 @@ GD void set_n_iter(Lane &L, int n) { L.mats = (L.mats & 0xFFF) | (n << 12); }
 
 template <unsigned MASK, class ACC>
 GD void lane_step2(const DevSceneView &sv, const TraceCtx &tx, int max_depth, double spp, int x, int y, unsigned long long base,
-                   Lane &L, Trav &tv, LanePriv2 &lp, ACC &acc, LaneCounters &lc, BounceLog *log) {
+                   Lane &L, Trav &tv, LanePriv2 &lp, ACC &acc, LaneCounters &lc, BounceLog *log, int replay_per_step) {
     const DevCamera &cam = sv.cam;
     const int w = cam.width, h = cam.height;
     const int st0 = L.st;
@@ -101,8 +102,10 @@ GD void lane_step2(const DevSceneView &sv, const TraceCtx &tx, int max_depth, do
         act = stop ? ACT_OFFSETS : ACT_BOUNCE;
     }
     // ---------------- offsets: validity of the primary hit, then replay of the logged iterations ----------------
-    bool off_done = false, off_alive = false, need_resample = false;
-    double log_p2 = 0;
+    // The replay runs as a loop inside this step (at most kReplayPerStep iterations, the rest continues as S_REPLAY in the
+    // next step): an iteration needs only sample + pdf of the offset's primary vertex, a fraction of a wave step, and a
+    // lane that replays holds no pending ray, so every step it spends in S_REPLAY is a trace phase it sits out.
+    bool off_done = false, off_alive = false;
     if (st0 == S_OFFSET) {
         if (hit && nv.material_id == L.mat0()) {                                    // :424-443
             L.f = L.dir; L.pdf = 1.0;                                               // o.dir, o.jacob
@@ -115,34 +118,45 @@ GD void lane_step2(const DevSceneView &sv, const TraceCtx &tx, int max_depth, do
     }
     if (st0 == S_REPLAY) off_alive = true;
     if (off_alive) {
-        const int r = L.kc >> 2;
-        if (r >= n_iter(L) || r >= kLogCap) { off_done = true; off_alive = (r >= n_iter(L)); }     // all iterations replayed
-        else {
+        int r = L.kc >> 2, budget = replay_per_step;
+        const int n_it = n_iter(L);
+        Pcg rs; rs.state = L.rng_state; rs.inc = L.rng_inc;
+        D3 odir = L.f;
+        double jac = L.pdf;
+        const GdptMaterial &om = tx.materials[nv.material_id];
+        for (;;) {
+            if (r >= n_it || r >= kLogCap) { off_done = true; off_alive = (r >= n_it); break; }       // all iterations replayed
             const BounceLog e = log[r * kBlock];
-            if (nv.material_id != e.mat) { off_done = true; off_alive = false; }    // :607-612
-            else if (e.p2 < 0) off_done = true;                                     // the base broke at pdf <= 0: no re-sampling
-            else { need_resample = true; log_p2 = e.p2; }
+            if (nv.material_id != e.mat) { off_done = true; off_alive = false; break; }              // :607-612
+            if (e.p2 < 0) { off_done = true; break; }                               // the base broke at pdf <= 0: no re-sampling
+            if (budget-- == 0) { L.st = S_REPLAY; break; }
+            D2 ruv; double rw;
+            ruv.x = pcg_real(rs); ruv.y = pcg_real(rs); rw = pcg_real(rs);          // the base path's numbers of this iteration
+            if (r + 2 >= sv.rr_depth) (void)pcg_next(rs);                           // skip its roulette draw
+            BsdfSample obs; obs.dir_out = splat(0); obs.eta = 0; obs.roughness = 0;
+            const D3 oview = -odir;
+            const bool osampled = bsdf_sample<false, true, MASK>(sv, om, oview, nv, ruv, rw, obs);
+            const double opdf = osampled ? bsdf_pdf<false, true, MASK>(sv, om, oview, obs.dir_out, nv) : 0.0;
+            if (!osampled || opdf <= 0.0) { off_done = true; off_alive = false; break; }             // :773-959
+            jac *= e.p2 / opdf; odir = obs.dir_out; r++;                            // :813, :815-816
         }
+        L.f = odir; L.pdf = jac; L.kc = (L.kc & 3) | (r << 2);
+        L.rng_state = rs.state;
     }
-    // ---------------- shared BSDF block ----------------
+    // ---------------- shared BSDF block (base path) ----------------
     bool sampled = false;
     BsdfSample bs; bs.dir_out = splat(0); bs.eta = 0; bs.roughness = 0;
     D3 f = splat(0);
     double pdf = 0;
-    if (act == ACT_BOUNCE || need_resample) {
+    if (act == ACT_BOUNCE) {
         D2 ruv; double rw;
         Pcg r; r.state = L.rng_state; r.inc = L.rng_inc;
-        ruv.x = pcg_real(r); ruv.y = pcg_real(r); rw = pcg_real(r);                 // :536-537 (base) / the same numbers (replay)
-        if (need_resample && ((L.kc >> 2) + 2 >= sv.rr_depth)) (void)pcg_next(r);   // skip the base path's roulette draw of this iteration
+        ruv.x = pcg_real(r); ruv.y = pcg_real(r); rw = pcg_real(r);                 // :536-537
         L.rng_state = r.state;
-        if (act == ACT_BOUNCE) lc.bounces++;
-        const D3 dir_view = (act == ACT_BOUNCE) ? -ray.dir : -L.f;
+        lc.bounces++;
+        const D3 dir_view = -ray.dir;
         sampled = mat_sample<false, false, true, MASK>(sv, tx, nv, dir_view, ruv, rw, bs);
         if (sampled) mat_eval_pdf<false, false, true, MASK>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
-    }
-    if (need_resample) {
-        if (!sampled || pdf <= 0.0) { off_done = true; off_alive = false; }         // :773-959
-        else { L.pdf *= log_p2 / pdf; L.f = bs.dir_out; L.kc += 4; L.st = S_REPLAY; }
     }
     if (off_done) {
         const int k = L.k();
@@ -251,7 +265,7 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_twosided(DevSceneView s
         trace_pending<TraceCfg<true, true, !LDS_SCENE>>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
         if (L.st == S_REPLAY || lane_ready(L, tv)) {
             if (tx.count) { tc.lane_steps++; if (wave_leader()) tc.wave_steps++; }
-            lane_step2<MASK>(sv, tx, a.max_depth, spp, x, y, base, L, tv, lp, acc, lc, log);
+            lane_step2<MASK>(sv, tx, a.max_depth, spp, x, y, base, L, tv, lp, acc, lc, log, a.replay_per_step);
         }
     }
     flush_counters(a, lc, tc, a.count != 0);
