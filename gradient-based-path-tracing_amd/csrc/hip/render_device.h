@@ -433,8 +433,8 @@ struct Lane {
 // the sample's stream, for the kernels with register headroom: the compiler already shares the derivation between the
 // two places that need it — 36 of 2883 vector instructions less, no change in run time.)
 template <bool LAMBERT, bool SERIAL_RNG, class ACC, class STAMPS = Stamps<false>, int PLAIN = 0>
-GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, double spp, int x, int y, unsigned long long base,
-                  Lane &L, Trav &tv, LanePriv &lp, ACC &acc, LaneCounters &lc, TraceCounters &tc, STAMPS *stp = nullptr) {
+GD int lane_consume(const DevSceneView &sv, const TraceCtx &tx, int max_depth, double spp, unsigned long long base,
+                    Lane &L, Trav &tv, LanePriv &lp, ACC &acc, LaneCounters &lc, TraceCounters &tc, STAMPS *stp = nullptr) {
     STAMPS none; STAMPS &stamps = stp ? *stp : none;
     const DevCamera &cam = sv.cam;
     const int w = cam.width, h = cam.height;
@@ -568,6 +568,17 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
         L.s++;
         if (L.s >= L.s_end) L.st = S_DONE; else act = ACT_PRIMARY_RAY;
     }
+    if (L.st == S_BOUNCE && act == ACT_BOUNCE) trav_init(sv, tv, __builtin_huge_val());       // a bounce ray was armed
+    return act;
+}
+
+// Second half of a lane's step: the camera ray of the next sample (ACT_PRIMARY_RAY) or of the next offset (ACT_OFFSET_RAY).
+// Separate from lane_consume so that the persistent kernels can hand a NEW ITEM to a lane whose item has just ended in
+// between: its first camera ray is then made in the same step instead of one trace phase later.
+template <bool SERIAL_RNG, class STAMPS = Stamps<false>>
+GD void lane_camera(const DevSceneView &sv, int act, int x, int y, unsigned long long base, Lane &L, Trav &tv, LanePriv &lp, STAMPS *stp = nullptr) {
+    STAMPS none; STAMPS &stamps = stp ? *stp : none;
+    const DevCamera &cam = sv.cam;
     if (act == ACT_PRIMARY_RAY || act == ACT_OFFSET_RAY) {
         double rx, ry;
         int ox = 0, oy = 0;
@@ -591,9 +602,17 @@ GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, dou
         Ray r = sample_primary<true>(cam, (x + ox) + rx, (y + oy) + ry, &fc, act == ACT_PRIMARY_RAY);
         if (act == ACT_PRIMARY_RAY) lp.set_fc(fc);
         L.org = r.org; L.dir = r.dir;
+        trav_init(sv, tv, __builtin_huge_val());                                    // a fresh pending ray
     }
-    if (L.st != S_DONE) trav_init(sv, tv, __builtin_huge_val());      // every surviving lane now holds a fresh pending ray
     stamps.mark(SEG_CAMERA);
+}
+
+// Both halves back to back (serial kernels, wavefront step kernel).
+template <bool LAMBERT, bool SERIAL_RNG, class ACC, class STAMPS = Stamps<false>, int PLAIN = 0>
+GD void lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, double spp, int x, int y, unsigned long long base,
+                  Lane &L, Trav &tv, LanePriv &lp, ACC &acc, LaneCounters &lc, TraceCounters &tc, STAMPS *stp = nullptr) {
+    const int act = lane_consume<LAMBERT, SERIAL_RNG, ACC, STAMPS, PLAIN>(sv, tx, max_depth, spp, base, L, tv, lp, acc, lc, tc, stp);
+    lane_camera<SERIAL_RNG, STAMPS>(sv, act, x, y, base, L, tv, lp, stp);
 }
 
 // The lane machine's two halves. trace_pending: traversal of the wave's unfinished pending rays, left when at most
@@ -803,7 +822,17 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
     unsigned long long t_dry = ~0ull;        // diagnostic build: wall clock (100 MHz) when this wave first found the queue empty
     if (STAMPED && (tid & 63) == 0) atomicMin(&a.counters->stamps[SEG_T_START], __builtin_amdgcn_s_memrealtime());
     for (;;) {
-        // ---- hand out work to idle lanes
+        // ---- (T) the wave's unfinished pending rays, then (S, first half) the lanes whose ray is done consume their hit
+        trace_pending<TraceCfg<WW, WIDE, !LDS_SCENE, !(PLAIN & kPlainNoSpheres)>>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
+        stamps.mark(SEG_TRACE);
+        stamps.tick(SEG_STEPS);
+        int act = ACT_NONE;
+        if (lane_ready(L, tv)) {
+            if (tx.count) { tc.lane_steps++; if (wave_leader()) tc.wave_steps++; }
+            act = lane_consume<LAMBERT, false, AccLds, Stamps<STAMPED>, PLAIN>(sv, tx, a.max_depth, spp, base, L, tv, lp, acc, lc, tc, &stamps);
+        }
+        // ---- hand out work to idle lanes: BETWEEN the two halves of the step, so that a lane whose item has just ended gets
+        // the first camera ray of its next item in this step and sits out no trace phase
         const bool idle = (L.st == S_DONE);
         if (idle && my_item >= 0) {                     // item finished: publish its 15 sums, clear the slot
             Accum r = acc.result();
@@ -825,18 +854,13 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
             const bool inside = item_to_pixel(a, W, (unsigned)my_item, x, y, s0, s1, s_chunks);
             base = ((unsigned long long)y * W + x) * (unsigned long long)a.spp;
             L.s = s0; L.s_end = s1;
-            L.st = (inside && s0 < s1) ? S_START : S_DONE;
+            if (inside && s0 < s1) act = ACT_PRIMARY_RAY;       // (an empty slot of a ragged edge tile stays S_DONE and is published as zeros)
         }
         stamps.mark(SEG_ITEM);
-        if (!__any(L.st != S_DONE)) { if (wq.exhausted) break; else continue; }
+        // ---- (S, second half) camera rays: next sample, next offset, first sample of a new item
+        lane_camera<false, Stamps<STAMPED>>(sv, act, x, y, base, L, tv, lp, &stamps);
+        if (!__any(L.st != S_DONE) && wq.exhausted) break;
         stamps.mark(SEG_QUEUE);
-        trace_pending<TraceCfg<WW, WIDE, !LDS_SCENE, !(PLAIN & kPlainNoSpheres)>>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
-        stamps.mark(SEG_TRACE);
-        stamps.tick(SEG_STEPS);
-        if (lane_ready(L, tv)) {
-            if (tx.count) { tc.lane_steps++; if (wave_leader()) tc.wave_steps++; }
-            lane_step<LAMBERT, false, AccLds, Stamps<STAMPED>, PLAIN>(sv, tx, a.max_depth, spp, x, y, base, L, tv, lp, acc, lc, tc, &stamps);
-        }
     }
     flush_counters(a, lc, tc, a.count != 0);
     if (STAMPED && (tid & 63) == 0) {
