@@ -47,19 +47,25 @@ struct LaneCounters { unsigned rays, bounces, nonfinite; };
 // lanes that sit it out wait for — the point of the exercise. The product kernels are built with ON = false: every call
 // below compiles to nothing. Stamp values only ever reach RenderCounters::stamps, never an output image.
 enum { SEG_QUEUE = 0, SEG_TRACE = 1, SEG_VERTEX = 2, SEG_CONSUME = 3, SEG_BSDF = 4, SEG_FINISH = 5, SEG_CAMERA = 6, SEG_STEPS = 7, SEG_PUBLISH = 8, SEG_TAKE = 9, SEG_ITEM = 10, SEG_COUNT = 12, SEG_T_START = 12, SEG_T_DRY = 13, SEG_T_END = 14, SEG_SLOTS = 16 };
+// The accumulators belong to the WAVE, not to a lane: they live in LDS (`slot` = the wave's row of 13 words) and every mark
+// is booked by the first ACTIVE lane. (Per-lane accumulators, as first built, book a step that a lane sits out onto that
+// lane's next mark: read from lane 0 they showed 13 % of the wave's time in "publish", which really takes 5 %.)
 template <bool ON> struct Stamps {
-    unsigned long long last, acc[SEG_COUNT];
-    GD void start() { if (ON) { for (int i = 0; i < SEG_COUNT; i++) acc[i] = 0; last = __builtin_amdgcn_s_memtime(); } }
+    unsigned long long *slot;                     // [SEG_COUNT] accumulators + [SEG_COUNT] = time of the previous mark
+    GD void start(unsigned long long *wave_row) {
+        if (ON) { slot = wave_row; if ((threadIdx.x & 63) == 0) { for (int i = 0; i < SEG_COUNT; i++) slot[i] = 0; slot[SEG_COUNT] = __builtin_amdgcn_s_memtime(); } }
+    }
     GD void mark(int seg) {                       // time since the previous mark belongs to `seg`
         if (ON) {
             __builtin_amdgcn_sched_barrier(0);
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the stamp has landed
-            acc[seg] += t - last; last = t;
+            if ((int)(threadIdx.x & 63) == __ffsll((unsigned long long)__ballot(1)) - 1) { slot[seg] += t - slot[SEG_COUNT]; slot[SEG_COUNT] = t; }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    GD void tick(int seg) { if (ON) acc[seg] += 1; }
+    GD void tick(int seg) { if (ON) { if ((int)(threadIdx.x & 63) == __ffsll((unsigned long long)__ballot(1)) - 1) slot[seg] += 1; } }
+    GD unsigned long long get(int seg) const { return ON ? slot[seg] : 0ull; }
 };
 struct Accum { D3 r, dx0, dy0, dx1, dy1; };
 
@@ -435,7 +441,7 @@ struct Lane {
 template <bool LAMBERT, bool SERIAL_RNG, class ACC, class STAMPS = Stamps<false>, int PLAIN = 0>
 GD int lane_consume(const DevSceneView &sv, const TraceCtx &tx, int max_depth, double spp, unsigned long long base,
                     Lane &L, Trav &tv, LanePriv &lp, ACC &acc, LaneCounters &lc, TraceCounters &tc, STAMPS *stp = nullptr) {
-    STAMPS none; STAMPS &stamps = stp ? *stp : none;
+    STAMPS none{}; STAMPS &stamps = stp ? *stp : none;
     const DevCamera &cam = sv.cam;
     const int w = cam.width, h = cam.height;
     const int st0 = L.st;
@@ -577,7 +583,7 @@ GD int lane_consume(const DevSceneView &sv, const TraceCtx &tx, int max_depth, d
 // between: its first camera ray is then made in the same step instead of one trace phase later.
 template <bool SERIAL_RNG, class STAMPS = Stamps<false>>
 GD void lane_camera(const DevSceneView &sv, int act, int x, int y, unsigned long long base, Lane &L, Trav &tv, LanePriv &lp, STAMPS *stp = nullptr) {
-    STAMPS none; STAMPS &stamps = stp ? *stp : none;
+    STAMPS none{}; STAMPS &stamps = stp ? *stp : none;
     const DevCamera &cam = sv.cam;
     if (act == ACT_PRIMARY_RAY || act == ACT_OFFSET_RAY) {
         double rx, ry;
@@ -817,22 +823,17 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
     unsigned long long base = 0;
     long long my_item = -1;
     WaveQueue wq;
+    __shared__ unsigned long long s_stamps[STAMPED ? (kBlock / 64) * (SEG_COUNT + 1) : 1];
     Stamps<STAMPED> stamps;
-    stamps.start();
+    stamps.start(s_stamps + (STAMPED ? (tid >> 6) * (SEG_COUNT + 1) : 0));
     unsigned long long t_dry = ~0ull;        // diagnostic build: wall clock (100 MHz) when this wave first found the queue empty
     if (STAMPED && (tid & 63) == 0) atomicMin(&a.counters->stamps[SEG_T_START], __builtin_amdgcn_s_memrealtime());
-    for (;;) {
-        // ---- (T) the wave's unfinished pending rays, then (S, first half) the lanes whose ray is done consume their hit
-        trace_pending<TraceCfg<WW, WIDE, !LDS_SCENE, !(PLAIN & kPlainNoSpheres)>>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
-        stamps.mark(SEG_TRACE);
-        stamps.tick(SEG_STEPS);
-        int act = ACT_NONE;
-        if (lane_ready(L, tv)) {
-            if (tx.count) { tc.lane_steps++; if (wave_leader()) tc.wave_steps++; }
-            act = lane_consume<LAMBERT, false, AccLds, Stamps<STAMPED>, PLAIN>(sv, tx, a.max_depth, spp, base, L, tv, lp, acc, lc, tc, &stamps);
-        }
-        // ---- hand out work to idle lanes: BETWEEN the two halves of the step, so that a lane whose item has just ended gets
-        // the first camera ray of its next item in this step and sits out no trace phase
+    // Work is handed out BETWEEN the two halves of a step in the Lambertian kernels (QUEUE_MID): a lane whose item has just
+    // ended gets the first camera ray of its next item in this step and sits out no trace phase (cbox 16 spp +2.8 %, sponza
+    // +2.4 %). The kernels with the full material switch keep the queue at the head of the loop: there the same move cost
+    // 3-5 % (one more block of live state across the BSDF switch; measured on disney_metal / disney_diffuse, same box).
+    constexpr bool QUEUE_MID = LAMBERT;
+    auto hand_out = [&](int &act) __attribute__((always_inline)) {
         const bool idle = (L.st == S_DONE);
         if (idle && my_item >= 0) {                     // item finished: publish its 15 sums, clear the slot
             Accum r = acc.result();
@@ -857,14 +858,35 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
             if (inside && s0 < s1) act = ACT_PRIMARY_RAY;       // (an empty slot of a ragged edge tile stays S_DONE and is published as zeros)
         }
         stamps.mark(SEG_ITEM);
+    };
+    for (;;) {
+        int act = ACT_NONE;
+        if (!QUEUE_MID) {
+            hand_out(act);
+            if (act == ACT_PRIMARY_RAY) L.st = S_START;         // lane_consume turns it into the first camera ray
+            if (!__any(L.st != S_DONE)) { if (wq.exhausted) break; else continue; }
+            stamps.mark(SEG_QUEUE);
+        }
+        // ---- (T) the wave's unfinished pending rays, then (S, first half) the lanes whose ray is done consume their hit
+        trace_pending<TraceCfg<WW, WIDE, !LDS_SCENE, !(PLAIN & kPlainNoSpheres)>>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
+        stamps.mark(SEG_TRACE);
+        stamps.tick(SEG_STEPS);
+        act = ACT_NONE;
+        if (lane_ready(L, tv)) {
+            if (tx.count) { tc.lane_steps++; if (wave_leader()) tc.wave_steps++; }
+            act = lane_consume<LAMBERT, false, AccLds, Stamps<STAMPED>, PLAIN>(sv, tx, a.max_depth, spp, base, L, tv, lp, acc, lc, tc, &stamps);
+        }
+        if (QUEUE_MID) hand_out(act);
         // ---- (S, second half) camera rays: next sample, next offset, first sample of a new item
         lane_camera<false, Stamps<STAMPED>>(sv, act, x, y, base, L, tv, lp, &stamps);
-        if (!__any(L.st != S_DONE) && wq.exhausted) break;
-        stamps.mark(SEG_QUEUE);
+        if (QUEUE_MID) {
+            if (!__any(L.st != S_DONE) && wq.exhausted) break;
+            stamps.mark(SEG_QUEUE);
+        }
     }
     flush_counters(a, lc, tc, a.count != 0);
     if (STAMPED && (tid & 63) == 0) {
-        for (int i = 0; i < SEG_COUNT; i++) atomicAdd(&a.counters->stamps[i], stamps.acc[i]);
+        for (int i = 0; i < SEG_COUNT; i++) atomicAdd(&a.counters->stamps[i], stamps.get(i));
         atomicMin(&a.counters->stamps[SEG_T_DRY], t_dry);
         atomicMax(&a.counters->stamps[SEG_T_END], __builtin_amdgcn_s_memrealtime());
     }
