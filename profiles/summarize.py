@@ -18,7 +18,7 @@ def one(pattern):
 ks = one(f"{tag}_stats/**/*kernel_stats.csv")
 if ks:
     shutil.copy(ks, os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"))
-b = os.path.join(out, f"{tag}_bench.json")
+b = os.path.join(out, f"{tag}_bench_under_rocprof.json")
 if os.path.exists(b):
     lines = [l for l in open(b) if l.startswith("{")]
     if lines:

@@ -260,6 +260,14 @@ def test_two_sided_lane_machine_replays_offsets_exactly(G, O, scene_tmp, scene, 
     for k in BUFS:
         assert rel_l2(got[k], full[k]) < 1e-12, k
     assert (fst.rays, fst.bounces) == (st.rays, st.bounces)
+    # offsets replay up to four logged iterations per wave step (render_twosided.h: kReplayPerStep): the budget is a
+    # schedule, not arithmetic — one iteration per step (as first built) or the whole log at once give the same bits
+    for budget in (1, 2, 1000):
+        with G.debug_knobs(replay_per_step=budget):
+            other, ost2 = sc.render(6, G.RNG_SAMPLE)
+        for k in BUFS:
+            assert np.array_equal(got[k], other[k], equal_nan=True), (budget, k)
+        assert (ost2.rays, ost2.bounces) == (st.rays, st.bounces)
     want, ost = O.OracleScene(sd.ptr, use_bvh=True).render(6, G.RNG_SAMPLE, threads=8)
     for k in BUFS:
         assert rel_l2(got[k], eager[k]) < 1e-12, k
@@ -284,6 +292,22 @@ def test_closest_hit_does_not_depend_on_the_tree(G, scene_tmp, rel, integ, monke
     for k in BUFS:
         assert np.array_equal(np.asarray(a[k]), np.asarray(b[k]), equal_nan=True), k
     assert sa.rays == sb.rays and sa.bounces == sb.bounces
+
+
+def test_kernel_without_sphere_and_texture_code_equals_the_general_one(G, scene_tmp):
+    """A scene of triangles with constant textures (cbox) runs a lane machine compiled without the sphere test and the
+    texture lookups (device_trace.h: PLAIN); the general Lambertian kernel must give the same bits, counters included —
+    LDS-resident and walked from HBM, with ragged edge tiles and items of several samples."""
+    for film, spp, extra in (((96, 80), 7, {}), ((200, 120), 24, {}), ((96, 80), 7, {"no_lds_scene": 1})):
+        sc = G.Scene(G.parse_scene(scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=film[0], height=film[1])))
+        with G.debug_knobs(**extra):
+            plain, ps = sc.render(spp, G.RNG_SAMPLE)
+        with G.debug_knobs(no_plain_kernel=1, **extra):
+            general, gs = sc.render(spp, G.RNG_SAMPLE)
+        for k in BUFS:
+            assert np.array_equal(plain[k], general[k]), (film, k)
+        assert (ps.rays, ps.bounces, ps.samples, ps.nonfinite_samples) == (gs.rays, gs.bounces, gs.samples, gs.nonfinite_samples)
+        assert np.abs(plain["cx0"]).max() > 0
 
 
 @pytest.mark.parametrize("rel, integ, film, spp", [("sponza/sponza.xml", None, (200, 112), 6), ("disney_bsdf_test/disney_metal.xml", "gradpath", (96, 80), 5),
