@@ -183,7 +183,23 @@ GD void lane_step2(const DevSceneView &sv, const TraceCtx &tx, int max_depth, do
             }
         }
     }
-    if (act == ACT_OFFSETS) { L.kc = 0; act = ACT_OFFSET_RAY; }
+    if (act == ACT_OFFSETS) {
+        // A base path whose PRIMARY vertex carries a one-sided lobe gets the lazy rule of render_device.h: only offsets that hit
+        // the same material are valid, and an offset on a one-sided lobe that survives the re-sampling of iteration 0 is retired
+        // by iteration 1 (its direction now points away from the surface, so the next sample_bsdf sees dir_in below it; a
+        // sampled direction below the geometric surface has pdf 0 and died in iteration 0). So once iteration 1 has run past
+        // its pdf test, all four offsets are dead whatever their primary rays would hit: contribX = 0, w = 1, no ray traced.
+        // (Iteration 1 broken at pdf <= 0 on a vertex of mat0 keeps them observable: C_BROKE_BOUNCE2 of the one-sided machine.)
+        const int n_it = n_iter(L), t0 = tx.materials[L.mat0()].type;
+        const bool one_sided0 = !(t0 == GDPT_MAT_DISNEY_GLASS || t0 == GDPT_MAT_DISNEY_BSDF || t0 == GDPT_MAT_ROUGHDIELECTRIC);
+        bool unobservable = false;
+        if (one_sided0 && n_it >= 2) {
+            const BounceLog e1 = log[1 * kBlock];
+            unobservable = (n_it >= 3) || !(e1.p2 < 0 && e1.mat == L.mat0());
+        }
+        if (unobservable) { acc_no_offsets(acc, lp.radiance(), L.contrib, L.prob, spp, lc); act = ACT_NEXT_SAMPLE; }
+        else { L.kc = 0; act = ACT_OFFSET_RAY; }
+    }
     if (act == ACT_NEXT_SAMPLE) {
         L.s++;
         if (L.s >= L.s_end) L.st = S_DONE; else act = ACT_PRIMARY_RAY;
