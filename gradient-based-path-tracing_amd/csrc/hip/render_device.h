@@ -237,6 +237,11 @@ GD void trav_init(const DevSceneView &sv, Trav &tv, double tfar) {
     tv.best.gid = -1; tv.best.t = (float)tfar; tv.best.u = tv.best.v = 0; tv.best.ngx = tv.best.ngy = tv.best.ngz = 0;
     tv.sp = 0; tv.cur = (sv.num_nodes == 0) ? kTravDone : 0;
 }
+// (Tried: stack entries that carry the child's box entry distance in their upper 11 bits — truncated fp32 exponent and three
+// mantissa bits beside a 21-bit child id, so no extra LDS — and are dropped at POP time when a closer hit has been found
+// since the push, instead of being fetched and tested first. Bit-identical images, and 6 % slower on cbox, 12 % on sponza
+// and the Disney scenes: the near-to-far order leaves few such entries, and the pop becomes a divergent loop of
+// dependent LDS reads that the whole wave waits for.)
 GD void trav_pop(const TraceCtx &tx, int &cur, int &sp) {
     if (sp > 0) { sp--; cur = tx.stack[sp * tx.stride]; } else cur = kTravDone;
 }
