@@ -533,6 +533,7 @@ void path_render_device_impl(GdptScene *sc, const GdptRenderParams *params, doub
     rl.thresh_a = env_int("keep_frac", -1); rl.thresh_c = env_int("search_frac", -1);
     rl.num_cus = sc->num_cus; rl.blocks_per_cu = env_int("blocks_per_cu", 0);
     rl.lambert_only = sc->lambert_only;
+    rl.no_spheres = sc->view.num_spheres == 0 && !env_int("no_plain_kernel", 0); rl.const_textures = sc->view.all_textures_constant != 0;
     rl.scene_fits_lds = !env_int("no_lds_scene", 0) &&
                         gdpt::scene_fits_lds_wide(sc->view.num_nodes4, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->view.num_lights, sc->wide_stack_need);
     {

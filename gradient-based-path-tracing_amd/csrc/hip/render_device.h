@@ -1146,6 +1146,6 @@ void launch_eager(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, hi
 void launch_tile_eager(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
 void launch_reconnect(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lambert, hipStream_t stream);
 void launch_path(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, hipStream_t stream);
-void launch_path_persistent(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lambert, hipStream_t stream);
+void launch_path_persistent(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lambert, bool plain, hipStream_t stream);
 void launch_tile_path(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
 } // namespace gdpt

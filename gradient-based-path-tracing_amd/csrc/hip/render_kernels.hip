@@ -168,7 +168,7 @@ void launch_path_render(const DevSceneView &sv, const RenderLaunch &rl, hipStrea
         long long blocks = (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2);
         if (blocks > (waves_needed + 3) / 4) blocks = (waves_needed + 3) / 4;
         if (blocks < 1) blocks = 1;
-        launch_path_persistent(sv, a, dim3((unsigned)blocks), rl.scene_fits_lds, rl.lambert_only, stream);
+        launch_path_persistent(sv, a, dim3((unsigned)blocks), rl.scene_fits_lds, rl.lambert_only, rl.no_spheres && rl.const_textures, stream);
     } else if (rl.rng_scheme == GDPT_RNG_SAMPLE) {
         // straight per-sample loop (A/B checks): static mapping, K = 2^log2k lanes per pixel
         long long pixels = (long long)W * rows;

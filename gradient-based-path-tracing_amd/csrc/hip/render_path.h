@@ -386,7 +386,8 @@ GD void path_trace_pending(const DevSceneView &sv, const TraceCtx &tx, const Pat
 
 // One step of a lane whose pending ray is finished (or that needs its first ray). ENV: the scene has an environment map
 // (compile-time so that scenes without one do not carry its code and registers).
-template <bool LAMBERT, bool ENV>
+// PLAIN: device_trace.h (scene without spheres / with constant textures only: that code is not compiled in).
+template <bool LAMBERT, bool ENV, int PLAIN = 0>
 GD void path_lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth, int x, int y, unsigned long long base,
                        PathLane &L, Trav &tv, PathPriv &lp, double *acc_slot, int acc_stride, LaneCounters &lc) {
     const DevCamera &cam = sv.cam;
@@ -399,12 +400,12 @@ GD void path_lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth
         lc.rays++;
         const bool hit = tv.best.gid >= 0;
         Ray ray; ray.org = L.org; ray.dir = L.dir_b; ray.tnear = 0; ray.tfar = __builtin_huge_val();
-        if (hit) make_vertex(sv, tx.tris, tx.need_uv, ray, tv.best, 0.0, (st0 == P_PRIMARY) ? 0.25 / (double)max(w, h) : 0.0, nv);
+        if (hit) make_vertex<PLAIN>(sv, tx.tris, tx.need_uv, ray, tv.best, 0.0, (st0 == P_PRIMARY) ? 0.25 / (double)max(w, h) : 0.0, nv);
         if (st0 == P_PRIMARY) {
             if (!hit) { lp.set_radiance(ENV ? envmap_emission(sv, -L.dir_b) : splat(0)); finish = true; }   // :31-43
             else {
                 lp.set_throughput(splat(1.0)); L.eta_scale = 1.0; L.num_vertices = 3;
-                lp.set_radiance((nv.light_id >= 0) ? emission(sv, nv, -L.dir_b) : splat(0));       // :76-79
+                lp.set_radiance((nv.light_id >= 0) ? emission(tx.lights, nv, -L.dir_b) : splat(0));       // :76-79
                 if (loop_allows(max_depth, 3)) shade = true; else finish = true;
             }
         } else {
@@ -414,7 +415,7 @@ GD void path_lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth
             const D3 T = lp.throughput();
             const double p2 = lp.pdf() * G;                                                        // :268 (pdf > 0 was checked at the vertex)
             if (hit && nv.light_id >= 0) {                                                         // :286-306, no MIS weight
-                const D3 Le = emission(sv, nv, -L.dir_b);
+                const D3 Le = emission(tx.lights, nv, -L.dir_b);
                 D3 C2 = G * f_b * Le;
                 C2 = C2 / p2;
                 lp.set_radiance(lp.radiance() + T * C2);
@@ -476,7 +477,7 @@ GD void path_lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth
             const double p1 = sv.light_pmf[light_id] * pdf_point_on_light(sv, light, pl, nv.position);
             if (G > 0 && p1 > 0) {
                 D3 f; double p2;
-                mat_eval_pdf<LAMBERT, true, true>(sv, tx, nv, dir_view, dir_light, f, p2);
+                mat_eval_pdf<LAMBERT, true, true, kAllMaterials, PLAIN>(sv, tx, nv, dir_view, dir_light, f, p2);
                 const D3 Le = (dot(pl.normal, -dir_light) <= 0) ? splat(0) : mk(light.intensity[0], light.intensity[1], light.intensity[2]);
                 D3 C1 = G * f * Le;
                 p2 *= G;
@@ -490,7 +491,7 @@ GD void path_lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth
             const double p1 = sv.light_pmf[light_id] * envmap_pdf(sv, -dir_light);
             if (p1 > 0) {
                 D3 f; double p2;
-                mat_eval_pdf<LAMBERT, true, true>(sv, tx, nv, dir_view, dir_light, f, p2);
+                mat_eval_pdf<LAMBERT, true, true, kAllMaterials, PLAIN>(sv, tx, nv, dir_view, dir_light, f, p2);
                 D3 C1 = 1.0 * f * envmap_emission(sv, -dir_light);
                 p2 *= 1.0;
                 const double w1 = (p1 * p1) / (p1 * p1 + p2 * p2);
@@ -507,7 +508,7 @@ GD void path_lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth
         if (mat_sample<LAMBERT, true, true>(sv, tx, nv, dir_view, ruv, rw, bs)) {                              // :200-203
             if (bs.eta != 0) L.eta_scale /= (bs.eta * bs.eta);
             D3 f; double pdf;
-            mat_eval_pdf<LAMBERT, true, true>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
+            mat_eval_pdf<LAMBERT, true, true, kAllMaterials, PLAIN>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
             if (pdf > 0) { L.bounce_valid = 1; L.dir_b = bs.dir_out; lp.set_f_pdf(f, pdf); }      // :263-266
         }
         L.org = nv.position;
@@ -539,7 +540,7 @@ GD void path_lane_step(const DevSceneView &sv, const TraceCtx &tx, int max_depth
     }
 }
 
-template <bool LAMBERT, bool LDS_SCENE, bool ENV>
+template <bool LAMBERT, bool LDS_SCENE, bool ENV, int PLAIN = 0>
 __global__ __launch_bounds__(kBlock, 2) void gdpt_path_persistent(DevSceneView sv, KernelArgs a) {
     constexpr int kLevels = LDS_SCENE ? kLdsSceneLevels : GDPT_BVH_MAX_DEPTH;
     __shared__ int s_stack[kLevels * kBlock];
@@ -582,10 +583,10 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_path_persistent(DevSceneView s
             L.st = (inside && s0 < s1) ? P_START : P_DONE;
         }
         if (!__any(L.st != P_DONE)) { if (wq.exhausted) break; else continue; }
-        path_trace_pending<TraceCfg<true, true, !LDS_SCENE>>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
+        path_trace_pending<TraceCfg<true, true, !LDS_SCENE, !(PLAIN & kPlainNoSpheres)>>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
         if (L.st == P_START || (path_lane_tracing(L.st) && tv.cur == kTravDone)) {
             if (tx.count) { tc.lane_steps++; if (wave_leader()) tc.wave_steps++; }
-            path_lane_step<LAMBERT, ENV>(sv, tx, a.max_depth, x, y, base, L, tv, lp, acc_slot, kBlock, lc);
+            path_lane_step<LAMBERT, ENV, PLAIN>(sv, tx, a.max_depth, x, y, base, L, tv, lp, acc_slot, kBlock, lc);
         }
     }
     flush_counters(a, lc, tc, a.count != 0);
@@ -613,6 +614,6 @@ __global__ __launch_bounds__(256) void gdpt_path_reduce(KernelArgs a, int W) {
 
 namespace gdpt {
 // one translation unit per kernel family (parallel compilation)
-void launch_path_persistent_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, hipStream_t stream);
+void launch_path_persistent_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool plain, hipStream_t stream);
 void launch_path_persistent_general(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, hipStream_t stream);
 } // namespace gdpt
