@@ -314,7 +314,7 @@ def bvh_check(bounds):
     b = np.ascontiguousarray(bounds, dtype=np.float32).reshape(-1, 6)
     st = (C.c_int32 * 8)()
     _check(lib().gdpt_bvh_check(b.ctypes.data_as(C.POINTER(C.c_float)), b.shape[0], st))
-    return dict(zip(("bvh2_nodes", "bvh2_depth", "wide_nodes", "wide_arity", "wide_stack_need", "leaves", "max_leaf_prims"), list(st)[:7]))
+    return dict(zip(("bvh2_nodes", "bvh2_depth", "wide_nodes", "wide_arity", "wide_stack_need", "leaves", "max_leaf_prims", "bvh8_nodes"), list(st)[:8]))
 
 
 def shape_triangle_bounds(scene_desc):

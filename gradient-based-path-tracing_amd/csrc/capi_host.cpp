@@ -188,6 +188,42 @@ int gdpt_bvh_check(const float *bounds6, int n, int32_t stats[8]) {
         }
         for (int i = 0; i < n; i++) if (seenw[i] != 1) throw std::runtime_error("gdpt_bvh_check: a primitive is not in exactly one wide leaf");
         stats[5] = leaves_keep; stats[6] = max_keep;
+        // 8-wide quantised form: the grid box of a child (evaluated exactly, in double) encloses its whole subtree
+        {
+            const std::vector<DevBvh8Node> &n8 = wide.nodes8;
+            stats[7] = (int32_t)n8.size();
+            if (wide.stack_need8 > GDPT_BVH_MAX_DEPTH + GDPT_STACK_OVERFLOW) throw std::runtime_error("gdpt_bvh_check: BVH8 stack bound exceeds the builder's maximum");
+            std::vector<Box> box8(n8.size());
+            std::vector<int> seen8((size_t)n, 0), need8(n8.size(), 0);
+            for (size_t i = n8.size(); i-- > 0;) {
+                const DevBvh8Node &nd = n8[i];
+                Box acc; for (int k = 0; k < 3; k++) { acc.lo[k] = INFINITY; acc.hi[k] = -INFINITY; }
+                int cnt = 0, sub = 0;
+                for (int k = 0; k < 3; k++) if (!(nd.scale[k] >= 0x1p-60f) || !std::isfinite(nd.scale[k])) throw std::runtime_error("gdpt_bvh_check: BVH8 grid step out of range");
+                for (int c = 0; c < 8; c++) {
+                    if (nd.child[c] == GDPT_CHILD_EMPTY) continue;
+                    cnt++;
+                    if (nd.child[c] >= 0 && (size_t)nd.child[c] <= i) throw std::runtime_error("gdpt_bvh_check: BVH8 child precedes its parent");
+                    if (nd.child[c] >= 0) sub = std::max(sub, need8[(size_t)nd.child[c]]);
+                    Box cb = nd.child[c] >= 0 ? box8[(size_t)nd.child[c]] : leaf_box(nd.child[c], &seen8);
+                    for (int k = 0; k < 3; k++) {
+                        const double lo = (double)nd.org[k] + (double)nd.qlo[k][c] * (double)nd.scale[k], hi = (double)nd.org[k] + (double)nd.qhi[k][c] * (double)nd.scale[k];
+                        if (!(lo <= (double)cb.lo[k] && (double)cb.hi[k] <= hi)) throw std::runtime_error("gdpt_bvh_check: BVH8 grid box does not enclose its subtree");
+                    }
+                }
+                need8[i] = std::max(0, cnt - 1) + sub;
+                // (a parent only has to enclose the primitives below it, not its children's grid boxes)
+                for (int c = 0; c < 8; c++) {
+                    if (nd.child[c] == GDPT_CHILD_EMPTY) continue;
+                    Box cb = nd.child[c] >= 0 ? box8[(size_t)nd.child[c]] : leaf_box(nd.child[c], nullptr);
+                    for (int k = 0; k < 3; k++) { acc.lo[k] = std::min(acc.lo[k], cb.lo[k]); acc.hi[k] = std::max(acc.hi[k], cb.hi[k]); }
+                }
+                box8[i] = acc;
+            }
+            if (!n8.empty() && need8[0] != wide.stack_need8) throw std::runtime_error("gdpt_bvh_check: BVH8 stack bound differs from the reported one");
+            for (int i = 0; i < n; i++) if (seen8[i] != 1) throw std::runtime_error("gdpt_bvh_check: a primitive is not in exactly one BVH8 leaf");
+            leaves = leaves_keep; max_leaf = max_keep;
+        }
     });
 }
 

@@ -9,6 +9,16 @@
 #define GDPT_BVH_MAX_DEPTH 32      // builder guarantee; traversal stack has this many slots per lane
 #define GDPT_LEAF_MAX_PRIMS 4
 #define GDPT_SPHERE_FLAG 0x80000000u
+#ifndef GDPT_HBM_BVH8
+#define GDPT_HBM_BVH8 0            // 1: scenes walked from HBM use the quantised 8-wide tree (A/B builds; measured slower)
+#endif
+// The BVH8's traversal-stack bound may exceed the LDS stack by this many slots: a lane whose stack grows past
+// GDPT_BVH_MAX_DEPTH entries (seven pushes per level make the bound of a full 8-wide tree 7 x its depth, although a ray
+// that hits every box of every level does not occur in practice) continues in a private array.
+#define GDPT_STACK_OVERFLOW 64
+#ifndef GDPT_BVH8_SORT
+#define GDPT_BVH8_SORT 1           // 1: hit children pushed far to near (sorted); 0: nearest first, the others in slot order
+#endif
 #define GDPT_CHILD_EMPTY INT32_MIN // child slot with no primitives (only in degenerate roots)
 
 // BVH2 node, 64 B, 64-B aligned: both children's boxes live in the parent so one fetch decides both.
@@ -28,6 +38,19 @@ struct DevBvh4Node {
     float hi[3][4];
     int32_t child[4];
     int32_t pad[4];
+};
+
+// BVH8 node, 128 B, 128-B aligned (scenes walked from HBM): eight child boxes, each bound one byte on a per-node grid
+// `org[axis] + q * scale[axis]`, lower bounds rounded down and upper bounds up, so a grid box
+// contains the fp32 box of the BVH2 it was made from (host/bvh.cpp: collapse_bvh8). One 128-byte fetch decides eight
+// subtrees. Child encoding as above; unused slots hold GDPT_CHILD_EMPTY.
+struct DevBvh8Node {
+    int32_t child[8];
+    uint8_t qlo[3][8];   // qlo[axis][child]  (offset 32: the 48 quantised bytes are three aligned 16-byte loads)
+    uint8_t qhi[3][8];
+    float org[3];
+    float scale[3];
+    int32_t pad[6];
 };
 
 // Traversal record of one primitive, 48 B, in BVH leaf order.
@@ -97,7 +120,8 @@ struct DevCamera {
 struct DevSceneView {
     DevCamera cam;
     const DevBvhNode *nodes;
-    const DevBvh4Node *nodes4;              // wide form of the same tree (HBM-resident scenes)
+    const DevBvh4Node *nodes4;              // wide form of the same tree (LDS-resident scenes)
+    const DevBvh8Node *nodes8;              // 8-wide quantised form (scenes walked from HBM)
     const DevPrim *prims;
     const DevTriShade *tris;
     const DevSphere *spheres;
@@ -118,7 +142,7 @@ struct DevSceneView {
     double env_scale;
     double env_to_world[16], env_to_local[16];
     const double *env_cdf_rows, *env_pdf_rows, *env_cdf_marginals, *env_pdf_marginals;
-    int32_t num_nodes, num_nodes4, num_prims, num_tris, num_spheres;
+    int32_t num_nodes, num_nodes4, num_nodes8, num_prims, num_tris, num_spheres;
     int32_t num_materials, num_lights, num_images;
     int32_t max_depth, rr_depth;
     int32_t all_textures_constant;          // no image / checkerboard texture anywhere: uv and footprints are unobservable

@@ -155,8 +155,11 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     // wide form for scenes walked from HBM (same padded boxes); narrower nodes if the stack bound would not hold
     gdpt::WideBvh wide = gdpt::collapse_for_traversal(bvh.nodes);
     if (wide.stack_need > GDPT_BVH_MAX_DEPTH) throw std::runtime_error("gdpt_scene_upload: BVH deeper than the traversal stack (builder bug)");
+    if (wide.stack_need8 > GDPT_BVH_MAX_DEPTH + GDPT_STACK_OVERFLOW) throw std::runtime_error("gdpt_scene_upload: BVH8 deeper than the traversal stack (builder bug)");
+    static_assert(sizeof(DevBvh8Node) == 128 && sizeof(DevBvh4Node) == 128, "wide BVH nodes are one 128-byte line");
     const std::vector<DevBvh4Node> &nodes4 = wide.nodes;
     sc->wide_stack_need = wide.stack_need;
+    sc->wide8_stack_need = wide.stack_need8;
     std::vector<DevPrim> prims(bvh.order.size());
     for (size_t i = 0; i < bvh.order.size(); i++) prims[i] = prim_in[ref_prim[bvh.order[i]]];
     sc->bvh_depth = bvh.depth;
@@ -270,6 +273,7 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     v.cam.inv_width = 1.0 / (double)cam.width; v.cam.inv_height = 1.0 / (double)cam.height;
     v.nodes = sc->keep(upload(bvh.nodes));
     v.nodes4 = sc->keep(upload(nodes4));
+    v.nodes8 = sc->keep(upload(wide.nodes8));
     v.prims = sc->keep(upload(prims));
     v.tris = sc->keep(upload(tris));
     v.spheres = sc->keep(upload(spheres));
@@ -281,7 +285,7 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     v.light_tri_cdf = sc->keep(upload(light_tri_cdf));
     v.light_tri_pos = sc->keep(upload(light_tri_pos)); v.light_tri_nrm = sc->keep(upload(light_tri_nrm));
     sc->has_envmap = desc->has_envmap != 0;
-    v.num_nodes = (int)bvh.nodes.size(); v.num_nodes4 = (int)nodes4.size(); v.num_prims = (int)prims.size();
+    v.num_nodes = (int)bvh.nodes.size(); v.num_nodes4 = (int)nodes4.size(); v.num_nodes8 = (int)wide.nodes8.size(); v.num_prims = (int)prims.size();
     v.num_tris = (int)tris.size(); v.num_spheres = (int)spheres.size();
     v.num_materials = desc->num_materials; v.num_lights = desc->num_lights; v.num_images = desc->num_images;
     v.max_depth = desc->max_depth; v.rr_depth = desc->rr_depth;
@@ -420,7 +424,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.count_traversal = stats && stats->nodes_visited == ~0ull;   // request flag: caller presets nodes_visited = UINT64_MAX
     rl.one_sided_materials = sc->one_sided && !sc->has_rough; rl.lambert_only = sc->lambert_only;
     rl.material_mask = sc->material_mask;
-    rl.wide_stack_need = sc->wide_stack_need; rl.num_materials = sc->view.num_materials;
+    rl.wide_stack_need = GDPT_HBM_BVH8 ? std::min(sc->wide8_stack_need, GDPT_BVH_MAX_DEPTH) : sc->wide_stack_need;   // LDS slots; the BVH8 may go on in private memory rl.num_materials = sc->view.num_materials;
     rl.scene_fits_lds = gdpt::scene_fits_lds(sc->view.num_nodes, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->view.num_lights, sc->bvh_depth);
     // A/B overrides of the parity tests (include/gdpt_debug.h); every default below is the product path
     auto env_int = [](const char *name, int def) { return gdpt::debug_knob_int(name, def); };

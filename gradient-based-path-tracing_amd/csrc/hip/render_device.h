@@ -158,6 +158,7 @@ GD void acc_no_offsets(ACC &a, D3 radiance, D3 contrib, double prob, double spp,
 struct TraceCtx {      // (every field is set by setup_trace or, for the wavefront kernels, by hand: keep the two in step)
     const DevBvhNode *nodes;
     const DevBvh4Node *nodes4;
+    const DevBvh8Node *nodes8;
     const DevPrim *prims;
     const DevTriShade *tris;
     const GdptMaterial *materials;
@@ -176,15 +177,35 @@ GD int pick4(unsigned k, int a0, int a1, int a2, int a3) {     // three v_cndmas
     const int lo = (k & 1u) ? a1 : a0, hi = (k & 1u) ? a3 : a2;
     return (k & 2u) ? hi : lo;
 }
+// SIGNED (scenes resident in LDS): the plane a ray enters a slab through is known from the sign of d, so the four near
+// bounds and the four far bounds of an axis are read from the row that holds them (lo or hi) instead of ordering the two
+// distances afterwards — same distances, same keys (rounding is monotonic), a third fewer instructions per child: cbox
+// +3.3 % (same-box A/B). On scenes walked from HBM the six address selects cost more than they save (16 instead of 4
+// spilled VGPRs in the general Lambertian kernel, sponza -10 %, the Disney scenes -1..-3 %), so those keep the ordered form.
+template <bool SIGNED>
 GD void visit_wide(const DevBvh4Node &n, const float oi[3], const float inv[3], float tnear, float tb, WideVisit &w) {
     const int c0 = n.child[0], c1 = n.child[1], c2 = n.child[2], c3 = n.child[3];
+    const char *base = (const char *)&n;
+    float nr[3][4], fr[3][4];
+    if (SIGNED) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const bool neg = inv[k] < 0.0f;                      // NaN (d = 0): either row, the distances are NaN and drop out
+            const float4 a = *(const float4 *)(base + (neg ? 48 + 16 * k : 16 * k)), b = *(const float4 *)(base + (neg ? 16 * k : 48 + 16 * k));
+            nr[k][0] = a.x; nr[k][1] = a.y; nr[k][2] = a.z; nr[k][3] = a.w;
+            fr[k][0] = b.x; fr[k][1] = b.y; fr[k][2] = b.z; fr[k][3] = b.w;
+        }
+    }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         float t0 = tnear, t1 = tb;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            float a = fmaf(n.lo[k][c], inv[k], -oi[k]), b = fmaf(n.hi[k][c], inv[k], -oi[k]);
-            t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));       // NaN (inf - inf, 0*inf) is dropped by fmin/fmax
+            if (SIGNED) { t0 = fmaxf(t0, fmaf(nr[k][c], inv[k], -oi[k])); t1 = fminf(t1, fmaf(fr[k][c], inv[k], -oi[k])); }
+            else {
+                float a = fmaf(n.lo[k][c], inv[k], -oi[k]), b = fmaf(n.hi[k][c], inv[k], -oi[k]);
+                t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));       // NaN (inf - inf, 0*inf) is dropped by fmin/fmax
+            }
         }
         const int ch = c == 0 ? c0 : (c == 1 ? c1 : (c == 2 ? c2 : c3));
         const bool h = (ch != GDPT_CHILD_EMPTY) && (t0 <= t1);   // see box_hit
@@ -195,6 +216,63 @@ GD void visit_wide(const DevBvh4Node &n, const float oi[3], const float inv[3], 
 #undef GDPT_CSWAP
 #pragma unroll
     for (int i = 0; i < 4; i++) w.ch[i] = pick4(w.key[i], c0, c1, c2, c3);
+}
+
+// One BVH8 node (scenes walked from HBM): eight child boxes, one byte per bound on the node's grid org + q * scale.
+// The slab distances are formed as fma(q, A, B) with A = scale / d and B = (org - o) / d per axis. A = fl(scale * fl(1/d))
+// and B = fma(org, fl(1/d), -fl(o/d)) round once each on top of 1/d and o/d, the final fma once: with e = 2^-24 a
+// computed distance differs from ((org + q scale) - o) / d by at most e (|q A| + |B| + |t|) beyond what 1/d and o/d
+// contribute (box_hit: e (|t| + |o/d|)), in total <= e (2E + 2E + 2E + 2E + E) / |d| = 5.4e-7 E / |d| — inside the
+// P / |d| = 1e-6 E / |d| by which the host's padding moved every plane before the boxes were put on the grid (rounded
+// outward there, verified in double).
+// The near plane of an axis is picked by the sign of d on whole dwords of four bounds (two v_cndmask per axis and
+// half), so a child costs six conversions, six fmas and two max3 / min3 pairs. Returns the hit children as keys sorted
+// near to far (entry distance with the slot in the low three bits).
+struct Wide8Visit { unsigned key[8]; };
+GD int pick8(unsigned k, const int c[8]) {     // seven v_cndmask
+    const int a0 = (k & 1u) ? c[1] : c[0], a1 = (k & 1u) ? c[3] : c[2], a2 = (k & 1u) ? c[5] : c[4], a3 = (k & 1u) ? c[7] : c[6];
+    const int b0 = (k & 2u) ? a1 : a0, b1 = (k & 2u) ? a3 : a2;
+    return (k & 4u) ? b1 : b0;
+}
+GD void visit_wide8(const DevBvh8Node &n, const float oi[3], const float inv[3], float tnear, float tb, int ch[8], Wide8Visit &w) {
+    const uint4 *qp = (const uint4 *)&n.qlo[0][0];
+    const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2];     // qlo x, y | qlo z, qhi x | qhi y, z
+    const unsigned lo[3][2] = {{q0.x, q0.y}, {q0.z, q0.w}, {q1.x, q1.y}};
+    const unsigned hi[3][2] = {{q1.z, q1.w}, {q2.x, q2.y}, {q2.z, q2.w}};
+    float A[3], B[3];
+    unsigned nq[3][2], fq[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        A[k] = n.scale[k] * inv[k];
+        B[k] = fmaf(n.org[k], inv[k], -oi[k]);
+        const bool neg = inv[k] < 0.0f;
+#pragma unroll
+        for (int h = 0; h < 2; h++) { nq[k][h] = neg ? hi[k][h] : lo[k][h]; fq[k][h] = neg ? lo[k][h] : hi[k][h]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++) ch[c] = n.child[c];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        float t0 = tnear, t1 = tb;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float qa = (float)((nq[k][c >> 2] >> (8 * (c & 3))) & 0xffu), qb = (float)((fq[k][c >> 2] >> (8 * (c & 3))) & 0xffu);
+            t0 = fmaxf(t0, fmaf(qa, A[k], B[k])); t1 = fminf(t1, fmaf(qb, A[k], B[k]));     // NaN (d = 0) is dropped by fmin/fmax
+        }
+        const bool h = (ch[c] != GDPT_CHILD_EMPTY) && (t0 <= t1);
+        w.key[c] = h ? ((__float_as_uint(t0) & ~7u) | (unsigned)c) : kMissKey;
+    }
+    if (!GDPT_BVH8_SORT) return;
+#define GDPT_CSWAP(i, j) { unsigned lo_ = min(w.key[i], w.key[j]), hi_ = max(w.key[i], w.key[j]); w.key[i] = lo_; w.key[j] = hi_; }
+    // 19-comparator network for eight keys
+    GDPT_CSWAP(0, 1) GDPT_CSWAP(2, 3) GDPT_CSWAP(4, 5) GDPT_CSWAP(6, 7)
+    GDPT_CSWAP(0, 2) GDPT_CSWAP(1, 3) GDPT_CSWAP(4, 6) GDPT_CSWAP(5, 7)
+    GDPT_CSWAP(1, 2) GDPT_CSWAP(5, 6) GDPT_CSWAP(0, 4) GDPT_CSWAP(3, 7)
+    GDPT_CSWAP(1, 5) GDPT_CSWAP(2, 6)
+    GDPT_CSWAP(1, 4) GDPT_CSWAP(3, 6)
+    GDPT_CSWAP(2, 4) GDPT_CSWAP(3, 5)
+    GDPT_CSWAP(3, 4)
+#undef GDPT_CSWAP
 }
 
 // A leaf holds 1..4 primitive records. All of them are fetched before the first test (indices clamped to the leaf, so
@@ -232,7 +310,7 @@ GD void test_leaf(const DevSceneView &sv, const TraceCtx &tx, int cur, const flo
 // first walk inner nodes until each holds a leaf (or has finished), then the leaves are intersected together (scenes
 // walked from HBM) — vs. one node or leaf per trip (scenes resident in LDS).
 constexpr int kTravDone = INT32_MIN;      // cur: >= 0 inner node, < 0 leaf (~cur = first << 2 | count-1), kTravDone finished
-struct Trav { Hit best; int cur, sp; };
+struct Trav { Hit best; int cur, sp; int ovf[GDPT_STACK_OVERFLOW]; };     // ovf: stack slots past the LDS column (BVH8 only; never touched otherwise)
 GD void trav_init(const DevSceneView &sv, Trav &tv, double tfar) {
     tv.best.gid = -1; tv.best.t = (float)tfar; tv.best.u = tv.best.v = 0; tv.best.ngx = tv.best.ngy = tv.best.ngz = 0;
     tv.sp = 0; tv.cur = (sv.num_nodes == 0) ? kTravDone : 0;
@@ -245,12 +323,44 @@ GD void trav_init(const DevSceneView &sv, Trav &tv, double tfar) {
 // since the push, instead of being fetched and tested first. Bit-identical images, and 6 % slower on cbox, 12 % on sponza
 // and the Disney scenes: the near-to-far order leaves few such entries, and the pop becomes a divergent loop of
 // dependent LDS reads that the whole wave waits for.)
-GD void trav_pop(const TraceCtx &tx, int &cur, int &sp) {
-    if (sp > 0) { sp--; cur = tx.stack[sp * tx.stride]; } else cur = kTravDone;
+// OVF: the tree's stack bound may exceed the LDS column (BVH8): slots from GDPT_BVH_MAX_DEPTH on live in the lane's private array.
+template <bool OVF = false>
+GD void trav_pop(const TraceCtx &tx, int &cur, int &sp, int *ovf = nullptr) {
+    if (sp > 0) {
+        sp--;
+        if (OVF && sp >= GDPT_BVH_MAX_DEPTH) cur = ovf[sp - GDPT_BVH_MAX_DEPTH];
+        else cur = tx.stack[sp * tx.stride];
+    } else cur = kTravDone;
+}
+template <bool OVF = false>
+GD void trav_push(const TraceCtx &tx, int &sp, int x, int *ovf = nullptr) {
+    if (OVF && sp >= GDPT_BVH_MAX_DEPTH) ovf[sp - GDPT_BVH_MAX_DEPTH] = x;
+    else tx.stack[sp * tx.stride] = x;
+    sp++;
 }
 template <bool WIDE, bool HBM = false>
-GD void trav_node(const TraceCtx &tx, const float oi[3], const float inv[3], float tnear, float tb, int &cur, int &sp) {
-    if (WIDE) {
+GD void trav_node(const TraceCtx &tx, const float oi[3], const float inv[3], float tnear, float tb, int &cur, int &sp, int *ovf) {
+    if (WIDE && HBM && GDPT_HBM_BVH8) {
+        Wide8Visit w;
+        int ch[8];
+        visit_wide8(tx.nodes8[cur], oi, inv, tnear, tb, ch, w);
+        if (GDPT_BVH8_SORT) {
+            if (w.key[0] != kMissKey) {
+#pragma unroll
+                for (int i = 7; i >= 1; i--) if (w.key[i] != kMissKey) trav_push<true>(tx, sp, pick8(w.key[i], ch), ovf);
+                cur = pick8(w.key[0], ch);
+            } else trav_pop<true>(tx, cur, sp, ovf);
+        } else {
+            unsigned near = w.key[0];
+#pragma unroll
+            for (int c = 1; c < 8; c++) near = min(near, w.key[c]);
+            if (near != kMissKey) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) if (w.key[c] != kMissKey && w.key[c] != near) trav_push<true>(tx, sp, ch[c], ovf);
+                cur = pick8(near, ch);
+            } else trav_pop<true>(tx, cur, sp, ovf);
+        }
+    } else if (WIDE) {
         WideVisit w;
 #ifdef GDPT_EXTRA_LOOKUPS     // experiment: seven more L1 lookups per node visit (hits), results unchanged
         if (HBM) {
@@ -262,11 +372,11 @@ GD void trav_node(const TraceCtx &tx, const float oi[3], const float inv[3], flo
                          : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6) : "v"(np) : "memory");
         }
 #endif
-        visit_wide(tx.nodes4[cur], oi, inv, tnear, tb, w);
+        visit_wide<!HBM>(tx.nodes4[cur], oi, inv, tnear, tb, w);
         if (w.key[0] != kMissKey) {
-            if (w.key[3] != kMissKey) { tx.stack[sp * tx.stride] = w.ch[3]; sp++; }
-            if (w.key[2] != kMissKey) { tx.stack[sp * tx.stride] = w.ch[2]; sp++; }
-            if (w.key[1] != kMissKey) { tx.stack[sp * tx.stride] = w.ch[1]; sp++; }
+            if (w.key[3] != kMissKey) trav_push(tx, sp, w.ch[3]);
+            if (w.key[2] != kMissKey) trav_push(tx, sp, w.ch[2]);
+            if (w.key[1] != kMissKey) trav_push(tx, sp, w.ch[1]);
             cur = w.ch[0];
         } else trav_pop(tx, cur, sp);
     } else {
@@ -277,7 +387,7 @@ GD void trav_node(const TraceCtx &tx, const float oi[3], const float inv[3], flo
         if (hl && hr) {
             int nearc = n.left, farc = n.right;
             if (tr < tl) { nearc = n.right; farc = n.left; }
-            tx.stack[sp * tx.stride] = farc; sp++;
+            trav_push(tx, sp, farc);
             cur = nearc;
         } else if (hl) cur = n.left;
         else if (hr) cur = n.right;
@@ -301,6 +411,7 @@ GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, flo
     // coordinate or the other axes reject)
 #pragma unroll
     for (int k = 0; k < 3; k++) if (d[k] == 0.0f) { inv[k] = __builtin_nanf(""); oi[k] = __builtin_nanf(""); }
+    constexpr bool kOvf = TC::WIDE && TC::FLAT && GDPT_HBM_BVH8;
     int cur = tv.cur, sp = tv.sp;
     Hit best = tv.best;
     for (;;) {
@@ -315,20 +426,20 @@ GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, flo
                 if (__popcll(__ballot(searching)) <= few) break;
                 if (searching) {
                     if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
-                    trav_node<TC::WIDE, TC::FLAT>(tx, oi, inv, tnear, best.t, cur, sp);
+                    trav_node<TC::WIDE, TC::FLAT>(tx, oi, inv, tnear, best.t, cur, sp, tv.ovf);
                 }
             }
             if (cur < 0 && cur != kTravDone) {
                 test_leaf<TC::FLAT, TC::SPHERES>(sv, tx, cur, o, d, tnear, tfar, best, tc);
-                trav_pop(tx, cur, sp);
+                trav_pop<kOvf>(tx, cur, sp, tv.ovf);
                 if (any_hit && best.gid >= 0) cur = kTravDone;
             }
         } else if (cur >= 0) {
             if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
-            trav_node<TC::WIDE, TC::FLAT>(tx, oi, inv, tnear, best.t, cur, sp);
+            trav_node<TC::WIDE, TC::FLAT>(tx, oi, inv, tnear, best.t, cur, sp, tv.ovf);
         } else if (cur != kTravDone) {
             test_leaf<TC::FLAT, TC::SPHERES>(sv, tx, cur, o, d, tnear, tfar, best, tc);
-            trav_pop(tx, cur, sp);
+            trav_pop<kOvf>(tx, cur, sp, tv.ovf);
             if (any_hit && best.gid >= 0) cur = kTravDone;
         }
     }
@@ -722,12 +833,12 @@ GD TraceCtx setup_trace(const DevSceneView &sv, unsigned char *s_scene, int *s_s
         for (int i = tid; i < lw; i += nthreads) dst[l0 + i] = s4[i];
         __syncthreads();
         tx.lights = (const double *)(s_scene + (size_t)l0 * 4);
-        tx.nodes = (const DevBvhNode *)s_scene; tx.nodes4 = (const DevBvh4Node *)s_scene;
+        tx.nodes = (const DevBvhNode *)s_scene; tx.nodes4 = (const DevBvh4Node *)s_scene; tx.nodes8 = nullptr;
         tx.prims = (const DevPrim *)(s_scene + (size_t)nw * 4);
         tx.tris = (const DevTriShade *)(s_scene + (size_t)(nw + pw) * 4);
         tx.materials = (const GdptMaterial *)(s_scene + (size_t)(nw + pw + tw) * 4);
     } else {
-        tx.nodes = sv.nodes; tx.nodes4 = sv.nodes4; tx.prims = sv.prims; tx.tris = sv.tris; tx.materials = sv.materials;
+        tx.nodes = sv.nodes; tx.nodes4 = sv.nodes4; tx.nodes8 = sv.nodes8; tx.prims = sv.prims; tx.tris = sv.tris; tx.materials = sv.materials;
         tx.lights = sv.light_intensity;
     }
     return tx;

@@ -32,7 +32,7 @@ struct RenderLaunch {
     int thresh_a, thresh_c;        // trace-phase exit fractions /256 (unfinished rays; lanes still searching a leaf), -1 = default
     int force_log2k;               // lanes per pixel = 2^force_log2k (-1 = automatic)
     bool lds_wide;                 // LDS-resident scene walked in its BVH4 form
-    int wide_stack_need;           // traversal-stack bound of the scene's BVH4 (host-verified)
+    int wide_stack_need;           // traversal-stack bound of the tree the HBM kernels walk (host-verified)
     int num_materials;
     unsigned material_mask;        // bit t = some material of the scene has type t (selects kernels built for small sets)
     bool two_sided_machine;        // two-sided lobes present (and no rough ones): lane machine with replayed offsets

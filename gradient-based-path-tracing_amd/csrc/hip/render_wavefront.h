@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kBlock) void gdpt_wf_step(DevSceneView sv, KernelAr
     TraceCtx tx;
     tx.count = false; tx.need_uv = !sv.all_textures_constant;
     tx.stack = nullptr; tx.stride = 0;
-    tx.nodes = sv.nodes; tx.nodes4 = sv.nodes4; tx.prims = sv.prims; tx.tris = sv.tris; tx.materials = sv.materials; tx.lights = sv.light_intensity;
+    tx.nodes = sv.nodes; tx.nodes4 = sv.nodes4; tx.nodes8 = sv.nodes8; tx.prims = sv.prims; tx.tris = sv.tris; tx.materials = sv.materials; tx.lights = sv.light_intensity;
     AccMem acc; acc.slot = (double *)(S + (long long)WF_ACC * N); acc.stride = N;
     LanePriv lp; lp.slot = (double *)(S + (long long)WF_PRIV * N); lp.stride = (int)N;
 
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kBlock, kWfTraceWaves) void gdpt_wf_trace(DevSceneV
     TraceCtx tx;
     tx.count = a.count != 0; tx.need_uv = false;
     tx.stack = s_stack + tid; tx.stride = kBlock;
-    tx.nodes = sv.nodes; tx.nodes4 = sv.nodes4; tx.prims = sv.prims; tx.tris = sv.tris; tx.materials = sv.materials; tx.lights = sv.light_intensity;
+    tx.nodes = sv.nodes; tx.nodes4 = sv.nodes4; tx.nodes8 = sv.nodes8; tx.prims = sv.prims; tx.tris = sv.tris; tx.materials = sv.materials; tx.lights = sv.light_intensity;
     TraceCounters tc = {0, 0, 0, 0, 0, 0};
     LaneCounters lc = {0, 0, 0};
     Trav tv;

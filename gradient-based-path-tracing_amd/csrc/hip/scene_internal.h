@@ -21,7 +21,8 @@ struct GdptScene {
     int device = 0;
     DevSceneView view{};
     int bvh_depth = 0;
-    int wide_stack_need = 0;
+    int wide_stack_need = 0;       // stack bound of the BVH4 (LDS-resident scenes)
+    int wide8_stack_need = 0;      // stack bound of the BVH8 (scenes walked from HBM)
     bool has_envmap = false;
     int scene_spp = 0;             // <sampler sampleCount> of the description (default spp)
     bool one_sided = true, lambert_only = true;

@@ -4,6 +4,8 @@
 #include "../capi_common.h"
 
 #include <cstdlib>
+#include <cstring>
+#include <stdexcept>
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -192,11 +194,15 @@ BvhBuildResult build_bvh(const std::vector<PrimBounds> &bounds) {
     return std::move(bld.out);
 }
 
-std::vector<DevBvh4Node> collapse_bvh4(const std::vector<DevBvhNode> &nodes, int max_children, int stack_slots, int *stack_need) {
-    std::vector<DevBvh4Node> out;
+namespace {
+// A node of the collapsed tree before it is written in a device format: up to 8 child boxes + child references.
+struct WideTmp { float lo[3][8], hi[3][8]; int32_t child[8]; int cnt; };
+
+std::vector<WideTmp> collapse_generic(const std::vector<DevBvhNode> &nodes, int max_children, int stack_slots, int *stack_need) {
+    std::vector<WideTmp> out;
     if (stack_need) *stack_need = 0;
     if (nodes.empty()) return out;
-    max_children = std::min(4, std::max(2, max_children));
+    max_children = std::min(8, std::max(2, max_children));
     struct Ref { float lo[3], hi[3]; int32_t child; };
     auto area = [](const Ref &r) {
         float dx = r.hi[0] - r.lo[0], dy = r.hi[1] - r.lo[1], dz = r.hi[2] - r.lo[2];
@@ -225,13 +231,13 @@ std::vector<DevBvh4Node> collapse_bvh4(const std::vector<DevBvhNode> &nodes, int
     }
     // A node that holds cnt children pushes up to cnt-1 entries before it descends, so each child inherits the node's
     // slot budget minus cnt-1. A subtree whose binary depth fits its budget can always be finished with arity 2, so the
-    // widest arity whose children all satisfy d2(child) <= budget-(cnt-1) is taken: the tree is 4-wide wherever the
-    // SAH tree is reasonably balanced and narrows only along unusually deep paths.
+    // widest arity whose children all satisfy d2(child) <= budget-(cnt-1) is taken: the tree is as wide as asked wherever
+    // the SAH tree is reasonably balanced and narrows only along unusually deep paths.
     struct Item { int32_t node; int budget; };
     std::vector<Item> queue{{0, stack_slots}};
     out.emplace_back();
     for (size_t qi = 0; qi < queue.size(); qi++) {
-        Ref refs[4];
+        Ref refs[8];
         int cnt = 0;
         for (int arity = max_children; arity >= 2; arity--) {
             cnt = refs_of(queue[qi].node, refs);
@@ -249,11 +255,12 @@ std::vector<DevBvh4Node> collapse_bvh4(const std::vector<DevBvhNode> &nodes, int
             for (int i = 0; i < cnt; i++) if (refs[i].child >= 0 && d2[(size_t)refs[i].child] > queue[qi].budget - (cnt - 1)) fits = false;
             if (fits) break;      // arity 2 of a subtree with d2 <= budget always fits
         }
-        DevBvh4Node nd;
-        for (int c = 0; c < 4; c++) {
+        WideTmp nd;
+        for (int c = 0; c < 8; c++) {
             for (int k = 0; k < 3; k++) { nd.lo[k][c] = std::numeric_limits<float>::infinity(); nd.hi[k][c] = -std::numeric_limits<float>::infinity(); }
-            nd.child[c] = GDPT_CHILD_EMPTY; nd.pad[c] = 0;
+            nd.child[c] = GDPT_CHILD_EMPTY;
         }
+        nd.cnt = cnt;
         for (int c = 0; c < cnt; c++) {
             for (int k = 0; k < 3; k++) { nd.lo[k][c] = refs[c].lo[k]; nd.hi[k][c] = refs[c].hi[k]; }
             if (refs[c].child >= 0) {
@@ -269,10 +276,66 @@ std::vector<DevBvh4Node> collapse_bvh4(const std::vector<DevBvhNode> &nodes, int
         std::vector<int> need(out.size(), 0);
         for (size_t i = out.size(); i-- > 0;) {
             int cnt = 0, sub = 0;
-            for (int c = 0; c < 4; c++) if (out[i].child[c] != GDPT_CHILD_EMPTY) { cnt++; if (out[i].child[c] >= 0) sub = std::max(sub, need[(size_t)out[i].child[c]]); }
+            for (int c = 0; c < 8; c++) if (out[i].child[c] != GDPT_CHILD_EMPTY) { cnt++; if (out[i].child[c] >= 0) sub = std::max(sub, need[(size_t)out[i].child[c]]); }
             need[i] = std::max(0, cnt - 1) + sub;
         }
         *stack_need = need[0];
+    }
+    return out;
+}
+} // namespace
+
+std::vector<DevBvh4Node> collapse_bvh4(const std::vector<DevBvhNode> &nodes, int max_children, int stack_slots, int *stack_need) {
+    std::vector<WideTmp> tmp = collapse_generic(nodes, std::min(4, max_children), stack_slots, stack_need);
+    std::vector<DevBvh4Node> out(tmp.size());
+    for (size_t i = 0; i < tmp.size(); i++) {
+        DevBvh4Node &nd = out[i];
+        for (int c = 0; c < 4; c++) {
+            for (int k = 0; k < 3; k++) { nd.lo[k][c] = tmp[i].lo[k][c]; nd.hi[k][c] = tmp[i].hi[k][c]; }
+            nd.child[c] = tmp[i].child[c]; nd.pad[c] = 0;
+        }
+    }
+    return out;
+}
+
+// Quantised 8-wide form. Per node and axis a grid `org + q * scale`, q = 0..255, scale = extent / 255 of the union of
+// the child boxes (rounded up to fp32); a child's lower bounds are rounded down and its upper bounds up on that grid,
+// checked in double precision, so the grid box always contains the fp32 box it replaces. Boxes grow by less than
+// extent / 255 per side.
+std::vector<DevBvh8Node> collapse_bvh8(const std::vector<DevBvhNode> &nodes, int stack_slots, int *stack_need) {
+    std::vector<WideTmp> tmp = collapse_generic(nodes, 8, stack_slots, stack_need);
+    std::vector<DevBvh8Node> out(tmp.size());
+    for (size_t i = 0; i < tmp.size(); i++) {
+        const WideTmp &w = tmp[i];
+        DevBvh8Node &nd = out[i];
+        std::memset(&nd, 0, sizeof(nd));
+        for (int c = 0; c < 8; c++) nd.child[c] = w.child[c];
+        for (int k = 0; k < 3; k++) {
+            float lo = std::numeric_limits<float>::infinity(), hi = -std::numeric_limits<float>::infinity();
+            for (int c = 0; c < w.cnt; c++) if (w.lo[k][c] <= w.hi[k][c]) { lo = std::min(lo, w.lo[k][c]); hi = std::max(hi, w.hi[k][c]); }
+            if (!(lo <= hi)) { lo = 0.f; hi = 0.f; }
+            const double ext = (double)hi - (double)lo;
+            // grid step: extent / 255 rounded up to fp32 (floor 2^-60: keeps step / d a normal number)
+            float step = (float)(ext / 255.0);
+            while ((double)step * 255.0 < ext) step = std::nextafterf(step, std::numeric_limits<float>::infinity());
+            step = std::max(step, 0x1p-60f);
+            for (int tries = 0;; tries++) {
+                const double sc = (double)step;
+                bool ok = true;
+                for (int c = 0; c < 8 && ok; c++) {
+                    if (c >= w.cnt || !(w.lo[k][c] <= w.hi[k][c])) { nd.qlo[k][c] = 255; nd.qhi[k][c] = 0; continue; }   // (empty slot: never read as a box, the child id decides)
+                    double ql = std::floor(((double)w.lo[k][c] - (double)lo) / sc), qh = std::ceil(((double)w.hi[k][c] - (double)lo) / sc);
+                    while (ql > 0 && (double)lo + ql * sc > (double)w.lo[k][c]) ql -= 1;
+                    while ((double)lo + qh * sc < (double)w.hi[k][c]) qh += 1;
+                    if (ql < 0) ql = 0;
+                    if (qh > 255) { ok = false; break; }
+                    nd.qlo[k][c] = (uint8_t)ql; nd.qhi[k][c] = (uint8_t)qh;
+                }
+                if (ok) { nd.org[k] = lo; nd.scale[k] = step; break; }
+                if (tries > 64 || !std::isfinite(step)) throw std::runtime_error("collapse_bvh8: box extent out of range");
+                step *= 1.0001f;
+            }
+        }
     }
     return out;
 }
@@ -280,6 +343,7 @@ std::vector<DevBvh4Node> collapse_bvh4(const std::vector<DevBvhNode> &nodes, int
 WideBvh collapse_for_traversal(const std::vector<DevBvhNode> &nodes) {
     WideBvh w;
     w.nodes = collapse_bvh4(nodes, 4, GDPT_BVH_MAX_DEPTH, &w.stack_need);
+    w.nodes8 = collapse_bvh8(nodes, GDPT_BVH_MAX_DEPTH + GDPT_STACK_OVERFLOW, &w.stack_need8);
     for (const DevBvh4Node &n : w.nodes) {
         int cnt = 0;
         for (int c = 0; c < 4; c++) cnt += (n.child[c] != GDPT_CHILD_EMPTY);

@@ -25,8 +25,12 @@ BvhBuildResult build_bvh(const std::vector<PrimBounds> &bounds);
 // BVH2's own depth must fit); `*stack_need` receives the bound actually reached.
 std::vector<DevBvh4Node> collapse_bvh4(const std::vector<DevBvhNode> &nodes, int max_children, int stack_slots, int *stack_need);
 
-// The wide tree the device walks (stack bound <= GDPT_BVH_MAX_DEPTH slots); arity = widest node present.
-struct WideBvh { std::vector<DevBvh4Node> nodes; int arity = 0, stack_need = 0; };
+// The same collapse to up to 8 children, written as DevBvh8Node (child boxes quantised to 8 bits on a per-node grid,
+// always enclosing the boxes they replace). Same stack rule.
+std::vector<DevBvh8Node> collapse_bvh8(const std::vector<DevBvhNode> &nodes, int stack_slots, int *stack_need);
+
+// The wide trees the device walks (stack bounds <= GDPT_BVH_MAX_DEPTH slots); arity = widest BVH4 node present.
+struct WideBvh { std::vector<DevBvh4Node> nodes; std::vector<DevBvh8Node> nodes8; int arity = 0, stack_need = 0, stack_need8 = 0; };
 WideBvh collapse_for_traversal(const std::vector<DevBvhNode> &nodes);
 
 } // namespace gdpt

@@ -323,8 +323,10 @@ void gdpt_image_free(double *texels);
  * Builds the acceleration structure that gdpt_scene_upload would build over `n` primitive boxes (bounds6 = n x
  * {min xyz, max xyz}, fp32) — the replacement for the reference's Embree commit, src/scene.cpp:20-31 — and verifies it:
  * every primitive sits in exactly one leaf, every child box encloses the boxes below it, in the BVH2 and in the
- * collapsed wide form. stats: [0] BVH2 nodes, [1] BVH2 depth, [2] wide nodes, [3] wide node arity used (2..4),
- * [4] traversal-stack bound of the wide form, [5] leaves, [6] max primitives per leaf, [7] 0. */
+ * collapsed wide forms (4-wide fp32 boxes; 8-wide boxes quantised on a per-node grid, whose exactly evaluated grid
+ * boxes must enclose their subtrees and whose stack bound must hold). stats: [0] BVH2 nodes, [1] BVH2 depth, [2] BVH4
+ * nodes, [3] BVH4 node arity used (2..4), [4] traversal-stack bound of the BVH4, [5] leaves, [6] max primitives per
+ * leaf, [7] BVH8 nodes. */
 int gdpt_bvh_check(const float *bounds6, int n, int32_t stats[8]);
 
 const char *gdpt_last_error(void);

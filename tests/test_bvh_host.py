@@ -25,6 +25,8 @@ def test_random_boxes(n):
     assert st["wide_stack_need"] <= 32 and st["bvh2_depth"] <= 32
     if n > 4:
         assert st["wide_nodes"] < st["bvh2_nodes"]
+    if n > 64:
+        assert st["bvh8_nodes"] < st["wide_nodes"]        # the quantised 8-wide form of the same tree (verified inside the check)
 
 
 def test_empty():
@@ -55,3 +57,4 @@ def test_scene_geometry(scene):
     st = G.bvh_check(b)
     print(scene, st)
     assert st["leaves"] > 0 and st["wide_stack_need"] <= 32
+    assert 0 < st["bvh8_nodes"] <= st["wide_nodes"]
