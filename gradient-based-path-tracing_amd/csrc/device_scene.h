@@ -19,6 +19,9 @@
 #ifndef GDPT_BVH8_SORT
 #define GDPT_BVH8_SORT 1           // 1: hit children pushed far to near (sorted); 0: nearest first, the others in slot order
 #endif
+#ifndef GDPT_SPEC_LEAF
+#define GDPT_SPEC_LEAF 0           // 1: every while-while walk sets leaves aside (A/B; the one-sided GradPath lane machine always does)
+#endif
 #define GDPT_CHILD_EMPTY INT32_MIN // child slot with no primitives (only in degenerate roots)
 
 // BVH2 node, 64 B, 64-B aligned: both children's boxes live in the parent so one fetch decides both.

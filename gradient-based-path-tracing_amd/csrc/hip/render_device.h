@@ -395,7 +395,8 @@ GD void trav_node(const TraceCtx &tx, const float oi[3], const float inv[3], flo
     }
 }
 // Compile-time traversal configuration of a kernel: loop order, tree form, leaf test style.
-template <bool WW_, bool WIDE_, bool FLAT_, bool SPHERES_ = true> struct TraceCfg { static constexpr bool WW = WW_, WIDE = WIDE_, FLAT = FLAT_, SPHERES = SPHERES_; };
+// SPEC (while-while order only): a lane that reaches a leaf sets it aside and goes on looking for its next one.
+template <bool WW_, bool WIDE_, bool FLAT_, bool SPHERES_ = true, bool SPEC_ = false> struct TraceCfg { static constexpr bool WW = WW_, WIDE = WIDE_, FLAT = FLAT_, SPHERES = SPHERES_, SPEC = SPEC_ || GDPT_SPEC_LEAF; };
 using TraceHbm = TraceCfg<true, true, true>;       // scenes walked from HBM
 
 // Called by the lanes whose ray is unfinished (tv.cur != kTravDone); the others of the wave sit it out.
@@ -421,18 +422,41 @@ GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, flo
             // inner nodes until at most search_frac/256 of the live lanes are still looking for their next leaf
             // (waiting for the last lane costs ~ln(64) mean search lengths); those lanes sit out the leaf tests.
             const int few = (live * search_frac) >> 8;
-            for (;;) {
-                const bool searching = cur >= 0;
-                if (__popcll(__ballot(searching)) <= few) break;
-                if (searching) {
-                    if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
-                    trav_node<TC::WIDE, TC::FLAT>(tx, oi, inv, tnear, best.t, cur, sp, tv.ovf);
+            if (TC::SPEC) {
+                // A lane that reaches a leaf sets it aside and goes on looking for its next one while the others are still
+                // searching (the nodes it visits meanwhile are tested against the hit distance it had before the leaf: a
+                // few more visits, never a different hit); the leaf set aside is intersected when the node loop is left, so
+                // no leaf is held across two rounds and the resumable state stays (cur, sp, best). One-sided lane machine,
+                // same-box A/B: sponza +3.3 % (20.2 instead of 19.4 nodes and 7.9 instead of 6.9 triangles per ray, 33.4
+                // instead of 35.0 trips per wave step), Disney metal / diffuse +2 %; the two-sided machine does not gain.
+                int held = kTravDone;
+                for (;;) {
+                    if (cur < 0 && cur != kTravDone && held == kTravDone) { held = cur; trav_pop<kOvf>(tx, cur, sp, tv.ovf); }
+                    const bool searching = cur >= 0;
+                    if (__popcll(__ballot(searching)) <= few) break;
+                    if (searching) {
+                        if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
+                        trav_node<TC::WIDE, TC::FLAT>(tx, oi, inv, tnear, best.t, cur, sp, tv.ovf);
+                    }
                 }
-            }
-            if (cur < 0 && cur != kTravDone) {
-                test_leaf<TC::FLAT, TC::SPHERES>(sv, tx, cur, o, d, tnear, tfar, best, tc);
-                trav_pop<kOvf>(tx, cur, sp, tv.ovf);
-                if (any_hit && best.gid >= 0) cur = kTravDone;
+                if (held != kTravDone) {
+                    test_leaf<TC::FLAT, TC::SPHERES>(sv, tx, held, o, d, tnear, tfar, best, tc);
+                    if (any_hit && best.gid >= 0) cur = kTravDone;
+                }
+            } else {
+                for (;;) {
+                    const bool searching = cur >= 0;
+                    if (__popcll(__ballot(searching)) <= few) break;
+                    if (searching) {
+                        if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
+                        trav_node<TC::WIDE, TC::FLAT>(tx, oi, inv, tnear, best.t, cur, sp, tv.ovf);
+                    }
+                }
+                if (cur < 0 && cur != kTravDone) {
+                    test_leaf<TC::FLAT, TC::SPHERES>(sv, tx, cur, o, d, tnear, tfar, best, tc);
+                    trav_pop<kOvf>(tx, cur, sp, tv.ovf);
+                    if (any_hit && best.gid >= 0) cur = kTravDone;
+                }
             }
         } else if (cur >= 0) {
             if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
@@ -987,7 +1011,7 @@ __global__ __launch_bounds__(kBlock, 2) void gdpt_render_phases(DevSceneView sv,
             stamps.mark(SEG_QUEUE);
         }
         // ---- (T) the wave's unfinished pending rays, then (S, first half) the lanes whose ray is done consume their hit
-        trace_pending<TraceCfg<WW, WIDE, !LDS_SCENE, !(PLAIN & kPlainNoSpheres)>>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
+        trace_pending<TraceCfg<WW, WIDE, !LDS_SCENE, !(PLAIN & kPlainNoSpheres), !LDS_SCENE>>(sv, tx, L, tv, a.thresh_a, a.thresh_c, tc);
         stamps.mark(SEG_TRACE);
         stamps.tick(SEG_STEPS);
         act = ACT_NONE;
