@@ -7,7 +7,7 @@ from helpers import scene_variant
 tmp = tempfile.mkdtemp()
 cases = [("cbox", "cbox/cbox_gdpt.xml", 512, 512, None, 64), ("sponza", "sponza/sponza.xml", 1280, 720, None, 16),
          ("disney_metal", "disney_bsdf_test/disney_metal.xml", 512, 512, "gradpath", 16)]
-for lm, lf in [(4, 1.0), (4, 0.8), (2, 0.8), (4, 0.8), (4, 1.0), (2, 1.0), (4, 0.8)]:
+for lm, lf in [(4, 0.8), (4, 0.6), (4, 1.0), (4, 1.3), (3, 0.8), (2, 0.8), (4, 0.8), (4, 0.5), (3, 0.6), (4, 0.7)]:
     G.debug_knobs.reset(); G.debug_knobs.set(bvh_leaf_max=lm, bvh_leaf_factor=lf)
     row = []
     for name, rel, w, h, integ, spp in cases:
