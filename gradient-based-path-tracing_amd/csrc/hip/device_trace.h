@@ -191,6 +191,7 @@ GD void shading_info_sphere(const DevSphere &sp, D2 st, D3 gn, D2 &uv, Frame &fr
 // PLAIN (what the scene does not contain, decided at upload): bit 0 = no spheres, bit 1 = every texture constant (uv and
 // the footprint are unobservable). The code for what is absent is not compiled in.
 constexpr int kPlainNoSpheres = 1, kPlainConstTex = 2, kPlainBoth = 3;
+constexpr int kPlainSetShift = 4;      // bits above: the material set a one-sided lane machine was built for (0 = every lobe)
 template <int PLAIN = 0>
 GD void make_vertex(const DevSceneView &sv, const DevTriShade *tris, bool need_uv, const Ray &ray, const Hit &h,
                     double rd_radius, double rd_spread, Vertex &v) {

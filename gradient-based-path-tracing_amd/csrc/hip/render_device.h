@@ -679,8 +679,10 @@ GD int lane_consume(const DevSceneView &sv, const TraceCtx &tx, int max_depth, d
             ruv.x = pcg_real(r2); ruv.y = pcg_real(r2); rw = pcg_real(r2);
         }
         const D3 dir_view = -ray.dir;
-        sampled = mat_sample<LAMBERT>(sv, tx, nv, dir_view, ruv, rw, bs);
-        if (sampled) mat_eval_pdf<LAMBERT, false, false, kAllMaterials, PLAIN>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
+        // (PLAIN >> kPlainSetShift: the scene's material set, if the kernel was built for a small one — render_phases_general_sets.hip)
+        constexpr unsigned kSet = (PLAIN >> kPlainSetShift) ? (unsigned)(PLAIN >> kPlainSetShift) : kAllMaterials;
+        sampled = mat_sample<LAMBERT, false, false, kSet>(sv, tx, nv, dir_view, ruv, rw, bs);
+        if (sampled) mat_eval_pdf<LAMBERT, false, false, kSet, PLAIN>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
     }
     stamps.mark(SEG_BSDF);
     if (st0 == S_OFFSET) {
@@ -1279,6 +1281,9 @@ void launch_phases_lambert_plain(const DevSceneView &sv, const gd::KernelArgs &a
 void launch_phases_lambert_stamped(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool plain, hipStream_t stream);   // diagnostic build
 void launch_reduce_partials(const DevSceneView &sv, const gd::KernelArgs &a, hipStream_t stream);
 void launch_phases_general(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, bool lds_wide, hipStream_t stream);
+// kernels built for {Lambertian, one Disney lobe} (render_phases_general_sets_*.hip): false if the scene's set is not one of theirs
+bool launch_phases_general_set_a(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, unsigned material_mask, hipStream_t stream);
+bool launch_phases_general_set_b(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, unsigned material_mask, hipStream_t stream);
 void launch_phases_twosided(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, bool lds, unsigned material_mask, void *bounce_log, hipStream_t stream);
 void launch_tile_phases_lambert(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);
 void launch_tile_phases_general(const DevSceneView &sv, const gd::KernelArgs &a, dim3 grid, int ntx, int nty, hipStream_t stream);

@@ -133,6 +133,7 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
             } else if (rl.lambert_only && rl.stamped && (!rl.scene_fits_lds || rl.lds_wide)) launch_phases_lambert_stamped(sv, a, grid, rl.scene_fits_lds, rl.no_spheres && rl.const_textures, stream);
             else if (rl.lambert_only && rl.no_spheres && (!rl.scene_fits_lds || rl.lds_wide)) launch_phases_lambert_plain(sv, a, grid, rl.scene_fits_lds, rl.const_textures, stream);
             else if (rl.lambert_only) launch_phases_lambert(sv, a, grid, rl.scene_fits_lds, rl.lds_wide, stream);
+            else if (!rl.scene_fits_lds && rl.no_spheres && (launch_phases_general_set_a(sv, a, grid, rl.material_mask, stream) || launch_phases_general_set_b(sv, a, grid, rl.material_mask, stream))) {}   // kernel built for the scene's material set
             else launch_phases_general(sv, a, grid, rl.scene_fits_lds, rl.lds_wide, stream);
             launch_reduce_partials(sv, a, stream);
         }

@@ -26,7 +26,7 @@
  *   wf_slots             (int)  wavefront pipeline: at most this many path slots (forces slots to run several items)
  *   replay_per_step (n >= 1)    two-sided lane machine: replay iterations of an offset per wave step (default 4; 1 = one per step)
  *   no_plain_kernel (0/1)       one-sided lane machine: the kernel with sphere and texture code even for a triangles-only, constant-texture scene
- *   full_material_switch (0/1)  two-sided lane machine: the kernel with the full material switch even when the scene fits a small set
+ *   full_material_switch (0/1)  lane machines: the kernel with the full material switch even when the scene fits a small set
  *   stamps               (0/1)  Lambertian lane machine: the diagnostic build with in-kernel cycle stamps; a render with
  *                               stats then leaves its per-segment wave cycles for gdpt_debug_get_stamps
  */
