@@ -323,6 +323,9 @@ GD void trav_init(const DevSceneView &sv, Trav &tv, double tfar) {
 // since the push, instead of being fetched and tested first. Bit-identical images, and 6 % slower on cbox, 12 % on sponza
 // and the Disney scenes: the near-to-far order leaves few such entries, and the pop becomes a divergent loop of
 // dependent LDS reads that the whole wave waits for.)
+// (Tried: the top of the stack in a register inside trav_run, so that a pop hands out a value that is already there and the LDS
+// read behind it refills the register off the critical path. Same bits, no spills, and 2-4 % slower on sponza and the Disney
+// scenes, 1-3 % on cbox: every push turns into a conditional store plus a move.)
 // OVF: the tree's stack bound may exceed the LDS column (BVH8): slots from GDPT_BVH_MAX_DEPTH on live in the lane's private array.
 template <bool OVF = false>
 GD void trav_pop(const TraceCtx &tx, int &cur, int &sp, int *ovf = nullptr) {
