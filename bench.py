@@ -7,7 +7,7 @@ in HBM when the timed region starts.
 
 N = 1: BASELINE.json configs[1] — cbox_gdpt geometry, 512x512, 16 spp, one MI355X.
 N > 1: the film is sharded into N contiguous bands of whole tile rows; every rank renders its band,
-       sends the last cy1 row to the rank below, assembles c, cx, cy for its band, ONE packed all-gather (RCCL) puts
+       sends the last cy1 row to the rank below, assembles c, cx, cy for its band, an in-place all-gather (RCCL) puts
        the three images on every rank, then the solve runs replicated — `gdpt_amd.sharding.ShardedGradPath.step`, the
        same object the gloo tests drive on CPU tensors. No collective inside the render.
        `value` is the weak-scaling figure (spp = 16*N on the same film: per-GPU work fixed); `scaling_strong` holds the
@@ -161,7 +161,7 @@ def pmc_child(args):
     sd = G.parse_scene(args.scene, film=film_of(args))
     sc = G.Scene(sd, device=0)
     shift = G.SHIFT_RECONNECT if args.shift == "reconnect" else G.SHIFT_REFERENCE
-    for _ in range(3):
+    for _ in range(10):                  # (pmc.kernel_times leaves every kernel's first launch out of its average)
         sc.gradient_path_render(spp=args.spp, rng_scheme=G.RNG_SAMPLE, alpha=args.alpha, shift=shift)
 
 
@@ -353,7 +353,7 @@ def run_rank(args):
                                f"({spp_total} spp total), render+assemble+Poisson(DCT-I as fp64 GEMM) per step"
                                + (" [shift=reconnect: extension mode, NOT the headline workload]" if args.shift == "reconnect" else ""),
                    "rng": "sample-stream PCG32",
-                   "sharding": f"{world} row bands, 1-row halo + one packed all-gather of c,cx,cy ({args.dist_backend})" if world > 1 else "single GPU",
+                   "sharding": f"{world} row bands, 1-row halo + in-place all-gather of c,cx,cy ({args.dist_backend})" if world > 1 else "single GPU",
                    "alpha": args.alpha},
         "render_ms": render_ms, "exchange_ms": ph["exchange"], "poisson_ms": ph["solve"],
         "render_msamples_per_s": W * (r1 - r0) * spp_total / render_ms / 1e3 if render_ms > 0 else 0.0,
@@ -371,7 +371,8 @@ def run_rank(args):
     roof = {"kernel": render_kernel, "launch_ms": render_ms,
             "model": {"what": "SURVEY.md 8(d) algorithmic bytes / launch time: rays*64 + nodes*node_bytes + prims*48 + bounces*320; "
                               "for an LDS-resident scene none of these bytes leave the CU, so this is NOT an HBM utilisation",
-                      "bound": "hbm", "achieved": model_gbs, "peak": pmc.HBM_PEAK_GBS, "unit": "GB/s", "frac": model_gbs / pmc.HBM_PEAK_GBS,
+                      "bound": "hbm", "achieved": model_gbs, "peak": pmc.HBM_PEAK_GBS, "unit": "GB/s",
+                      "model_bytes_per_second_over_hbm_peak": model_gbs / pmc.HBM_PEAK_GBS,
                       "algorithmic_bytes_per_launch": alg_bytes, "nodes_per_ray": cs.nodes_visited / max(1, cs.rays),
                       "node_bytes": cs.node_bytes, "prims_per_ray": cs.tris_tested / max(1, cs.rays)}}
     kernels = []
@@ -390,11 +391,12 @@ def run_rank(args):
             "achieved": vs.get("fp64_tflops"), "frac": (vs["fp64_tflops"] / pmc.VECTOR_FP64_PEAK_TFLOPS) if "fp64_tflops" in vs else None,
             "what": "vector-fp64 issue (no MFMA on this path): achieved = (2 FMA + ADD + MUL + TRANS f64 wave-instructions) * 64 * lane_util / launch "
                     "time, peak = MI355X vector fp64; lane_util, valu_share and wait_share say where the rest goes",
-            "lane_util": vs.get("lane_util"), "valu_share_of_wave_time": vs.get("valu_share"), "wait_share_of_wave_time": vs.get("wait_share"),
+            "lane_util": vs.get("lane_util"), "valu_busy_share_of_launch": vs.get("valu_busy"), "issue_slot_frac": vs.get("issue_slot_frac"),
+            "valu_share_of_wave_time": vs.get("valu_share"), "wait_share_of_wave_time": vs.get("wait_share"),
             "issue_stall_share_of_wave_time": vs.get("issue_stall_share"), "fp32_tflops": vs.get("fp32_tflops"),
             "traffic": traffic, "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (2*FETCH+WRITE KB, gfx950 correction)",
             "hbm_frac_counters": (traffic / (launch_us * 1e-6) / 1e9 / pmc.HBM_PEAK_GBS) if traffic else None,
-            "launch_us_rocprof": launch_us, "pmc_errors": got["errors"] or None})
+            "launch_us_rocprof": launch_us, "launch_us_first": tms["first_us"] if tms else None, "pmc_errors": got["errors"] or None})
         kernels = _kernel_lines(got, W, H, spp_total, pmc)
         if os.path.abspath(args.scene) == os.path.abspath(DEFAULT_SCENE) and os.path.exists(SPONZA):
             result["secondary_hbm_scene"] = _sponza_block(pmc, work, args)
@@ -408,6 +410,16 @@ def run_rank(args):
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        # the checker is built -O2 for every box; the baseline leg times the same source compiled for THIS box's cores
+        flags = ["-O3", "-march=native", "-std=c++17", "-fPIC", "-ffp-contract=off", "-pthread", "-w"]
+        native = os.path.join(tempfile.mkdtemp(prefix="gdpt_oracle_"), "liboracle_native.so")
+        try:
+            subprocess.run(["g++"] + flags + ["-shared", "-o", native, os.path.join(ROOT, "oracle", "oracle.cpp")], check=True, timeout=300,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            os.environ["GDPT_ORACLE_SO"] = native
+            oracle_build = "g++ " + " ".join(flags[:-1])
+        except Exception:        # noqa: BLE001 (no compiler on the box: the -O2 checker build is timed instead, and the line says so)
+            oracle_build = "g++ -O2 -ffp-contract=off (oracle/Makefile; the -O3 -march=native build failed on this box)"
         import oracle_py as O
         cores = host_cores()
         osc = O.OracleScene(sd.ptr, use_bvh=True)
@@ -418,6 +430,10 @@ def run_rank(args):
         cpu_poisson_ms = (time.perf_counter() - tp) * 1e3
         result["cpu_baseline"] = {"value": ost.samples / ost.seconds / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
                                   "cpu": cpu_model(),
+                                  "oracle_build": oracle_build,
+                                  "reference_itself": "SURVEY.md §6: the reference's own binary (gcc 11 -O2, Embree replaced by a brute-force 38-triangle shim) "
+                                                      "ran this scene at ~0.85 Msamples/s on 8 Xeon vCPUs @2.1 GHz in the survey container; it cannot run on "
+                                                      "the GPU box (no Embree, only this repository travels)",
                                   "sample": f"oracle (CPU restatement, tile-stream RNG, {cores} threads) on the same {W}x{H} scene at "
                                             f"{args.cpu_spp} spp = {ost.samples} samples in {ost.seconds:.2f} s; "
                                             f"scipy DCT-I Poisson {cpu_poisson_ms:.1f} ms on 1 core",

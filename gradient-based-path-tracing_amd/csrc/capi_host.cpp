@@ -25,7 +25,7 @@ namespace {
 std::mutex g_knob_mu;
 std::map<std::string, double> g_knobs;     // test-only overrides, include/gdpt_debug.h
 const char *const kKnobNames[] = {"force_eager", "log2k", "keep_frac", "search_frac", "blocks_per_cu", "no_lds_scene", "lds_wide",
-                                  "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "stamps", "wavefront", "wf_slots", "full_material_switch", "no_plain_kernel", "replay_per_step"};
+                                  "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "stamps", "wavefront", "wf_slots", "wf_sort", "multi_fail_band", "multi_fail_stage", "full_material_switch", "no_plain_kernel", "replay_per_step"};
 double g_stamps[16] = {0};
 } // namespace
 void debug_store_stamps(const unsigned long long *v, int n) {
@@ -114,7 +114,7 @@ int gdpt_bvh_check(const float *bounds6, int n, int32_t stats[8]) {
         std::vector<gdpt::PrimBounds> b((size_t)n);
         for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) { b[i].bmin[k] = bounds6[6 * i + k]; b[i].bmax[k] = bounds6[6 * i + 3 + k]; }
         gdpt::BvhBuildResult r = gdpt::build_bvh(b);
-        gdpt::WideBvh wide = gdpt::collapse_for_traversal(r.nodes);
+        gdpt::WideBvh wide = gdpt::collapse_for_traversal(r.nodes, true);
         std::memset(stats, 0, 8 * sizeof(int32_t));
         stats[0] = (int32_t)r.nodes.size(); stats[1] = r.depth;
         stats[2] = (int32_t)wide.nodes.size(); stats[3] = wide.arity; stats[4] = wide.stack_need;

@@ -153,7 +153,9 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
             }
     }
     // wide form for scenes walked from HBM (same padded boxes); narrower nodes if the stack bound would not hold
-    gdpt::WideBvh wide = gdpt::collapse_for_traversal(bvh.nodes);
+    // (the 8-wide quantised form is built, verified and uploaded only by the GDPT_HBM_BVH8 A/B library: a product upload neither
+    // pays for it nor can fail on it)
+    gdpt::WideBvh wide = gdpt::collapse_for_traversal(bvh.nodes, GDPT_HBM_BVH8 != 0);
     if (wide.stack_need > GDPT_BVH_MAX_DEPTH) throw std::runtime_error("gdpt_scene_upload: BVH deeper than the traversal stack (builder bug)");
     if (wide.stack_need8 > GDPT_BVH_MAX_DEPTH + GDPT_STACK_OVERFLOW) throw std::runtime_error("gdpt_scene_upload: BVH8 deeper than the traversal stack (builder bug)");
     static_assert(sizeof(DevBvh8Node) == 128 && sizeof(DevBvh4Node) == 128, "wide BVH nodes are one 128-byte line");
@@ -300,6 +302,7 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     // get_intersection_epsilon (src/scene.h:100-102) from Embree-style fp32 scene bounds (src/scene.cpp:29-33)
     double dx = (double)ub[0] - (double)lb[0], dy = (double)ub[1] - (double)lb[1], dz = (double)ub[2] - (double)lb[2];
     double radius = prims.empty() ? 0.0 : std::sqrt(dx * dx + dy * dy + dz * dz) / 2;
+    for (int k = 0; k < 3; k++) { sc->bounds[k] = lb[k]; sc->bounds[3 + k] = ub[k]; }
     v.isect_eps = std::min(radius * 1e-5, 0.01);
 
     // ---- environment map (Integrator::Path): TableDist2D over luminance * sin(elevation) of the level-0 image
@@ -424,7 +427,8 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.count_traversal = stats && stats->nodes_visited == ~0ull;   // request flag: caller presets nodes_visited = UINT64_MAX
     rl.one_sided_materials = sc->one_sided && !sc->has_rough; rl.lambert_only = sc->lambert_only;
     rl.material_mask = sc->material_mask;
-    rl.wide_stack_need = GDPT_HBM_BVH8 ? std::min(sc->wide8_stack_need, GDPT_BVH_MAX_DEPTH) : sc->wide_stack_need;   // LDS slots; the BVH8 may go on in private memory rl.num_materials = sc->view.num_materials;
+    rl.wide_stack_need = GDPT_HBM_BVH8 ? std::min(sc->wide8_stack_need, GDPT_BVH_MAX_DEPTH) : sc->wide_stack_need;   // LDS slots; the BVH8 may go on in private memory
+    rl.num_materials = sc->view.num_materials;
     rl.scene_fits_lds = gdpt::scene_fits_lds(sc->view.num_nodes, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->view.num_lights, sc->bvh_depth);
     // A/B overrides of the parity tests (include/gdpt_debug.h); every default below is the product path
     auto env_int = [](const char *name, int def) { return gdpt::debug_knob_int(name, def); };
@@ -475,9 +479,11 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
             ck(hipStreamSynchronize(stream), "hipStreamSynchronize");
             if (sc->d_wf_state) hipFree(sc->d_wf_state);
             if (sc->d_wf_live) hipFree(sc->d_wf_live);
-            sc->d_wf_state = nullptr; sc->d_wf_live = nullptr; sc->wf_slots = 0;
+            if (sc->d_wf_aux) hipFree(sc->d_wf_aux);
+            sc->d_wf_state = nullptr; sc->d_wf_live = nullptr; sc->d_wf_aux = nullptr; sc->wf_slots = 0;
             ck(hipMalloc((void **)&sc->d_wf_state, (size_t)slots * gdpt::wf_words() * sizeof(unsigned long long)), "hipMalloc(wavefront state)");
             ck(hipMalloc((void **)&sc->d_wf_live, (size_t)slots * sizeof(unsigned)), "hipMalloc(wavefront live list)");
+            ck(hipMalloc(&sc->d_wf_aux, gdpt::wf_aux_bytes(slots)), "hipMalloc(wavefront ray / hit records)");
             sc->wf_slots = slots;
         }
         if (!sc->d_wf_counters) {
@@ -485,6 +491,8 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
             ck(hipHostMalloc((void **)&sc->h_wf_word, sizeof(unsigned)), "hipHostMalloc(wavefront)");
             ck(hipEventCreateWithFlags(&sc->wf_event, hipEventDisableTiming), "hipEventCreate");
         }
+        rl.wf_aux = sc->d_wf_aux; rl.wf_sort = env_int("wf_sort", 1);
+        for (int k = 0; k < 6; k++) rl.wf_bounds[k] = sc->bounds[k];
         rl.wf_state = sc->d_wf_state; rl.wf_live = sc->d_wf_live; rl.wf_counters = sc->d_wf_counters; rl.wf_host = sc->h_wf_word;
         rl.wf_event = sc->wf_event; rl.wf_slots = slots;       // exactly the slots this band needs (the buffers may be larger)
     }
@@ -674,6 +682,14 @@ int gdpt_assemble_device(int width, int height, const double *d_img, const doubl
     return gdpt_assemble_rows_device(width, height, 0, 0, d_img, d_cx0, d_cy0, d_cx1, d_cy1, d_c, d_cx, d_cy, stream);
 }
 
+int gdpt_poisson_forget_stream(void *stream) {
+    return gdpt::guarded([&]() {
+        int dev = 0;
+        ck(hipGetDevice(&dev), "hipGetDevice");
+        gdpt::poisson_forget_stream(dev, (hipStream_t)stream);
+    });
+}
+
 int gdpt_poisson_solve_device(int width, int height, const double *d_c, const double *d_gx, const double *d_gy,
                               double dataCost, double *d_out, int solver, double tol, int max_iters,
                               void *stream, GdptPoissonStats *stats) {
@@ -710,7 +726,7 @@ int gdpt_poisson_solve_ex(int width, int height, const double *imgData, const do
 
 int gdpt_poisson_solve(int width, int height, const double *imgData, const double *imgGradX, const double *imgGradY,
                        double dataCost, double *imgOut) {
-    return gdpt_poisson_solve_ex(width, height, imgData, imgGradX, imgGradY, dataCost, imgOut, GDPT_SOLVER_DCT, 0.0, 0, nullptr);
+    return gdpt_poisson_solve_ex(width, height, imgData, imgGradX, imgGradY, dataCost, imgOut, GDPT_SOLVER_DEFAULT, 0.0, 0, nullptr);
 }
 
 int gdpt_gradient_path_render(GdptScene *scene, const GdptRenderParams *params, double dataCost, double *out_image,
@@ -728,7 +744,7 @@ int gdpt_gradient_path_render(GdptScene *scene, const GdptRenderParams *params, 
         GdptRenderStats local{};
         render_device_impl(scene, &p, scene->scene_spp, b[0], b[1], b[2], b[3], b[4], nullptr, rstats ? rstats : &local);
         gdpt::launch_assemble(w, h, 0, 0, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], nullptr);
-        gdpt::PoissonResult r = gdpt::poisson_solve_device(w, h, b[5], b[6], b[7], dataCost, b[8], GDPT_SOLVER_DCT, 0.0, 0, nullptr, pstats != nullptr);
+        gdpt::PoissonResult r = gdpt::poisson_solve_device(w, h, b[5], b[6], b[7], dataCost, b[8], GDPT_SOLVER_DEFAULT, 0.0, 0, nullptr, pstats != nullptr);
         if (pstats) { pstats->iterations = r.iterations; pstats->solver = r.solver; pstats->rel_residual = r.rel_residual; pstats->solve_ms = r.solve_ms; }
         ck(hipMemcpy(out_image, b[8], elems * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
         double *host[5] = {img, cx0, cy0, cx1, cy1};

@@ -57,16 +57,23 @@ void band_rows(int height, int n, int b, int *r0, int *r1) {
     *r1 = std::min(t1 * kTile, height);
 }
 
-// Reusable barrier for the per-device host threads of one call (C++17: no std::barrier).
+// Reusable barrier for the per-device host threads of one call (C++17: no std::barrier). Every arrival carries the
+// rank's own verdict ("I have failed"); the verdict of the ROUND — has anyone? — is formed under the barrier's lock by the
+// last arriver and handed to every participant, so all ranks take the same branch behind it. (Reading the other ranks'
+// error strings after the barrier, as an earlier version did, raced with ranks that were already writing theirs in the
+// next stage and could give two ranks different answers: one would enter a collective the other skips.)
 class HostBarrier {
     std::mutex mu; std::condition_variable cv; int n, waiting = 0; unsigned long long generation = 0;
+    bool any = false, verdict = false;
 public:
     explicit HostBarrier(int n_) : n(n_) {}
-    void arrive_and_wait() {
+    bool arrive_and_wait(bool failed) {
         std::unique_lock<std::mutex> lk(mu);
         const unsigned long long gen = generation;
-        if (++waiting == n) { waiting = 0; generation++; cv.notify_all(); }
+        any = any || failed;
+        if (++waiting == n) { verdict = any; any = false; waiting = 0; generation++; cv.notify_all(); }
         else cv.wait(lk, [&] { return generation != gen; });
+        return verdict;       // (stable until every waiter of this round has left: the next round needs all n arrivals)
     }
 };
 
@@ -84,11 +91,24 @@ struct Rank {
 
 } // namespace
 
+namespace { struct Job { const GdptRenderParams *params = nullptr; double alpha = 0; HostBarrier *bar = nullptr; bool want_stats = false; }; }
+
 struct GdptMulti {
     int n = 0, w = 0, h = 0, exchange = GDPT_EXCHANGE_RCCL, scene_spp = 0;
     bool equal_bands = false;
+    bool comms_aborted = false;    // a failure behind the first collective tore the communicators down: the handle is spent
     std::vector<Rank> ranks;
+    // one host thread per device 1..n-1, started once and parked between calls (device 0 is driven by the caller, as
+    // parallel_for's caller takes part in the tile loop, src/parallel.cpp:204-236)
+    std::vector<std::thread> workers;
+    std::mutex job_mu; std::condition_variable job_cv, done_cv;
+    unsigned long long job_gen = 0; int done = 0; bool quit = false;
+    Job job;
+    void start_workers();
     ~GdptMulti() {
+        { std::lock_guard<std::mutex> lk(job_mu); quit = true; }
+        job_cv.notify_all();
+        for (auto &t : workers) t.join();
         for (Rank &r : ranks) {
             hipSetDevice(r.device);
             if (r.comm) ncclCommDestroy(r.comm);
@@ -96,7 +116,7 @@ struct GdptMulti {
             for (hipEvent_t &e : r.ev_t) if (e) hipEventDestroy(e);
             if (r.ev_rendered) hipEventDestroy(r.ev_rendered);
             if (r.ev_pushed) hipEventDestroy(r.ev_pushed);
-            if (r.stream) hipStreamDestroy(r.stream);
+            if (r.stream) { gdpt::poisson_forget_stream(r.device, r.stream); hipStreamDestroy(r.stream); }   // the solver's per-stream scratch goes with the stream
             r.scene.reset();
         }
     }
@@ -105,43 +125,53 @@ struct GdptMulti {
 namespace {
 
 // Everything one device does for one call; runs on that device's host thread.
+// Four stages, three agreed checkpoints. A rank that fails in a stage still arrives at the checkpoint behind it, says so,
+// and every rank leaves together:
+//   A (after the render)            nothing that can block has been enqueued: everyone just stands down.
+//   B (after halo + band assembly)  a halo send / receive may be waiting for a peer that never posted its half;
+//   C (after the all-gather)        likewise a collective some ranks entered and one did not. RCCL: every rank aborts its
+//                                   communicator (ncclCommAbort ends the pending kernels), the handle is marked spent.
+//                                   Peer copies wait on events only, and every event is recorded whatever happened.
+// Test instrument (include/gdpt_debug.h: multi_fail_band / multi_fail_stage): throws in the named band and stage.
 void rank_body(GdptMulti *m, int i, const GdptRenderParams *params, double alpha, HostBarrier *bar, bool want_stats) {
     Rank &me = m->ranks[(size_t)i];
     const int W = m->w, H = m->h, n = m->n;
     const size_t row = (size_t)W * 3;
-    auto fail_safe = [&](auto &&fn) {            // a failing rank must still meet the others at every barrier
+    auto fail_safe = [&](auto &&fn) {            // a failing rank must still meet the others at every checkpoint
         if (!me.error.empty()) return;
         try { fn(); } catch (const std::exception &e) { me.error = e.what(); }
     };
+    const int fail_band = gdpt::debug_knob_int("multi_fail_band", -1), fail_stage = gdpt::debug_knob_int("multi_fail_stage", 0);
+    auto inject = [&](int stage) { if (fail_band == i && fail_stage == stage) throw std::runtime_error("injected failure (stage " + std::to_string(stage) + ")"); };
+    auto stand_down = [&](bool collectives_pending) {
+        if (me.error.empty()) me.error = "skipped: another device of the set failed";
+        if (collectives_pending && me.comm) { ncclCommAbort(me.comm); me.comm = nullptr; m->comms_aborted = true; }   // (every rank writes the same value)
+        hipSetDevice(me.device);
+        hipStreamSynchronize(me.stream);
+    };
     const bool owns = me.row_end > me.row_begin;
+    // ---- stage 1: render own band
     fail_safe([&] {
         ck(hipSetDevice(me.device), "hipSetDevice");
         ck(hipEventRecord(me.ev_t[0], me.stream), "hipEventRecord");
+        inject(1);
         if (owns) {
             GdptRenderParams p = params ? *params : GdptRenderParams{};
             p.row_begin = me.row_begin; p.row_end = me.row_end;
             if (me.row_begin == 0 && me.row_end == 0) throw std::runtime_error("empty band");   // (0,0) would mean "whole image"
             gdpt::render_device_impl(me.scene.get(), &p, m->scene_spp, me.buf[0], me.buf[1], me.buf[2], me.buf[3], me.buf[4], me.stream, nullptr);
         }
-        ck(hipEventRecord(me.ev_rendered, me.stream), "hipEventRecord");
-        ck(hipEventRecord(me.ev_t[1], me.stream), "hipEventRecord");
     });
+    // (recorded whatever happened: the peer-copy transport of the rank below waits on it)
+    hipSetDevice(me.device); hipEventRecord(me.ev_rendered, me.stream); hipEventRecord(me.ev_t[1], me.stream);
     // neighbours in band order that own rows (ranks without rows are skipped, as sharding.halo_exchange_cy1 does)
     int prev = -1, next = -1;
     for (int j = i - 1; j >= 0; j--) if (m->ranks[(size_t)j].row_end > m->ranks[(size_t)j].row_begin) { prev = j; break; }
     for (int j = i + 1; j < n; j++) if (m->ranks[(size_t)j].row_end > m->ranks[(size_t)j].row_begin) { next = j; break; }
-    bar->arrive_and_wait();                       // every ev_rendered is recorded
-    // a device that failed so far must not leave the others waiting inside a collective: everyone skips the exchange
-    bool any_failed = false;
-    for (const Rank &r : m->ranks) any_failed = any_failed || !r.error.empty();
-    if (any_failed) {
-        if (me.error.empty()) me.error = "skipped: another device of the set failed";
-        bar->arrive_and_wait();
-        hipStreamSynchronize(me.stream);
-        return;
-    }
-    // ---- halo: the last cy1 row of my band goes to the next band's device (row r1-1 of ITS cy1 image)
+    if (bar->arrive_and_wait(!me.error.empty())) { stand_down(false); return; }               // checkpoint A (every ev_rendered is recorded)
+    // ---- stage 2: halo — the last cy1 row of my band goes to the next band's device (row r1-1 of ITS cy1 image) — and assembly
     fail_safe([&] {
+        inject(2);
         if (!owns) return;
         if (m->exchange == GDPT_EXCHANGE_RCCL) {
             if (n > 1) {
@@ -156,11 +186,13 @@ void rank_body(GdptMulti *m, int i, const GdptRenderParams *params, double alpha
             ck(hipMemcpyPeerAsync(me.buf[4] + (size_t)(me.row_begin - 1) * row, me.device,
                                   up.buf[4] + (size_t)(up.row_end - 1) * row, up.device, row * sizeof(double), me.stream), "hipMemcpyPeerAsync(halo)");
         }
-        // ---- assemble own band (src/render.cpp:340-350)
+        // assemble own band (src/render.cpp:340-350)
         gdpt::launch_assemble(W, H, me.row_begin, me.row_end, me.buf[0], me.buf[1], me.buf[2], me.buf[3], me.buf[4], me.buf[5], me.buf[6], me.buf[7], me.stream);
     });
-    // ---- all-gather of c, cx, cy
+    if (bar->arrive_and_wait(!me.error.empty())) { stand_down(true); return; }                // checkpoint B
+    // ---- stage 3: all-gather of c, cx, cy
     fail_safe([&] {
+        inject(3);
         if (n == 1) return;
         if (m->exchange == GDPT_EXCHANGE_RCCL) {
             nk(ncclGroupStart(), "ncclGroupStart");
@@ -190,14 +222,16 @@ void rank_body(GdptMulti *m, int i, const GdptRenderParams *params, double alpha
             }
         }
     });
-    fail_safe([&] { ck(hipEventRecord(me.ev_pushed, me.stream), "hipEventRecord"); });
-    bar->arrive_and_wait();                       // every ev_pushed is recorded
+    hipSetDevice(me.device); hipEventRecord(me.ev_pushed, me.stream);
+    if (bar->arrive_and_wait(!me.error.empty())) { stand_down(true); return; }                // checkpoint C (every ev_pushed is recorded)
+    // ---- stage 4: solve on the first device
     fail_safe([&] {
         if (m->exchange == GDPT_EXCHANGE_PEER_COPY && i == 0)
             for (int j = 1; j < n; j++) ck(hipStreamWaitEvent(me.stream, m->ranks[(size_t)j].ev_pushed, 0), "hipStreamWaitEvent");
         ck(hipEventRecord(me.ev_t[2], me.stream), "hipEventRecord");
+        inject(4);
         if (i == 0) {
-            gdpt::poisson_solve_device(W, H, me.buf[5], me.buf[6], me.buf[7], alpha, me.buf[8], GDPT_SOLVER_DCT, 0.0, 0, me.stream, false);
+            gdpt::poisson_solve_device(W, H, me.buf[5], me.buf[6], me.buf[7], alpha, me.buf[8], GDPT_SOLVER_DEFAULT, 0.0, 0, me.stream, false);
         }
         ck(hipEventRecord(me.ev_t[3], me.stream), "hipEventRecord");
         ck(hipStreamSynchronize(me.stream), "hipStreamSynchronize");
@@ -212,9 +246,28 @@ void rank_body(GdptMulti *m, int i, const GdptRenderParams *params, double alpha
             me.rstats.render_ms = ms;
         }
     });
+    if (!me.error.empty()) { hipSetDevice(me.device); hipStreamSynchronize(me.stream); }     // (a failed solve: nothing of this call stays in flight)
+}
+
+void worker_loop(GdptMulti *m, int i) {
+    unsigned long long seen = 0;
+    for (;;) {
+        Job job;
+        {
+            std::unique_lock<std::mutex> lk(m->job_mu);
+            m->job_cv.wait(lk, [&] { return m->quit || m->job_gen != seen; });
+            if (m->quit) return;
+            seen = m->job_gen; job = m->job;
+        }
+        rank_body(m, i, job.params, job.alpha, job.bar, job.want_stats);
+        { std::lock_guard<std::mutex> lk(m->job_mu); m->done++; }
+        m->done_cv.notify_one();
+    }
 }
 
 } // namespace
+
+void GdptMulti::start_workers() { for (int i = 1; i < n; i++) workers.emplace_back(worker_loop, this, i); }
 
 extern "C" {
 
@@ -282,6 +335,7 @@ int gdpt_multi_create(const GdptSceneDesc *desc, const GdptMultiConfig *cfg, Gdp
             nk(ncclCommInitAll(comms.data(), n, cfg->devices), "ncclCommInitAll");
             for (int i = 0; i < n; i++) m->ranks[(size_t)i].comm = comms[(size_t)i];
         }
+        m->start_workers();
         *out = m.release();
     });
 }
@@ -297,11 +351,15 @@ int gdpt_multi_gradient_path_render(GdptMulti *m, const GdptRenderParams *params
         const auto t0 = std::chrono::steady_clock::now();
         HostBarrier bar(m->n);
         const bool want = rstats != nullptr || mstats != nullptr;
+        if (m->comms_aborted) throw std::runtime_error("gdpt_multi_gradient_path_render: an earlier call failed inside the exchange and its RCCL communicators were aborted; create a new handle");
         for (Rank &r : m->ranks) r.error.clear();
-        std::vector<std::thread> threads;
-        for (int i = 1; i < m->n; i++) threads.emplace_back(rank_body, m, i, params, dataCost, &bar, want);
-        rank_body(m, 0, params, dataCost, &bar, want);        // the calling thread drives device 0, as parallel_for's caller
-        for (auto &t : threads) t.join();                     // takes part in the tile loop (src/parallel.cpp:204-236)
+        {   // hand the call to the parked device threads; the calling thread drives device 0
+            std::lock_guard<std::mutex> lk(m->job_mu);
+            m->job = Job{params, dataCost, &bar, want}; m->done = 0; m->job_gen++;
+        }
+        m->job_cv.notify_all();
+        rank_body(m, 0, params, dataCost, &bar, want);
+        { std::unique_lock<std::mutex> lk(m->job_mu); m->done_cv.wait(lk, [&] { return m->done == m->n - 1; }); }
         for (int pass = 0; pass < 2; pass++)                  // report the device that failed, not the ones that stood down for it
             for (int i = 0; i < m->n; i++) {
                 const std::string &e = m->ranks[(size_t)i].error;

@@ -18,6 +18,8 @@ void launch_assemble(int w, int h, int row_begin, int row_end, const double *img
 PoissonResult poisson_solve_device(int w, int h, const double *d_c, const double *d_gx, const double *d_gy, double alpha,
                                    double *d_out, int solver, double tol, int max_iters, hipStream_t stream, bool timed);
 
+// Drops the (device, stream) pair's scratch state; call before destroying a stream the solver has run on (nothing in flight).
+void poisson_forget_stream(int dev, hipStream_t stream);
 void poisson_release_workspace();
 
 } // namespace gdpt

@@ -594,6 +594,25 @@ PoissonResult poisson_dct(int dev, DctWorkspace &ws, int w, int h, const double 
 
 } // namespace
 
+// Drops what the solver keeps for one (device, stream) pair — scratch buffers, rocBLAS handle, timing events. Owners of a
+// stream call it before destroying the stream: the registry is keyed by the handle's value, and a later stream that reuses
+// that value must not inherit another stream's state. The caller guarantees no solve is in flight on the pair.
+void poisson_forget_stream(int dev, hipStream_t stream) {
+    std::unique_ptr<StreamState> gone;
+    {
+        std::lock_guard<std::mutex> lk(g_registry_mu);
+        auto it = g_streams.find({dev, stream});
+        if (it == g_streams.end()) return;
+        gone = std::move(it->second);
+        g_streams.erase(it);
+    }
+    int cur = 0;
+    hipGetDevice(&cur);
+    hipSetDevice(dev);
+    gone->cg.release(); gone->dct.release();
+    hipSetDevice(cur);
+}
+
 void poisson_release_workspace() {
     std::lock_guard<std::mutex> lk(g_registry_mu);
     int cur = 0;

@@ -44,6 +44,9 @@ struct RenderLaunch {
     bool wavefront;
     unsigned long long *wf_state;  // device, wf_words() * wf_slots 8-byte words
     unsigned *wf_live;             // device, wf_slots
+    void *wf_aux;                  // device, wf_aux_bytes(wf_slots): ray / hit records, sort keys, histogram, overflow stacks
+    int wf_sort;                   // 0 = queue in slot order, 1 = sorted (octant, origin cell), 2 = sorted (origin cell, octant)
+    float wf_bounds[6];            // scene bounds (min xyz, max xyz) for the origin cells of the sort key
     unsigned *wf_counters;         // device, 3 * wf_max_generations()
     unsigned *wf_host;             // pinned, 1 word (live-count read-back)
     hipEvent_t wf_event;
@@ -70,6 +73,7 @@ int wf_words();
 int wf_max_generations();
 // Path slots of the wavefront pipeline for a band of `num_items` work items.
 int wf_slot_count(long long num_items);
+size_t wf_aux_bytes(int slots);
 // Enqueues the five-buffer render on `stream`. Throws std::runtime_error on a launch failure.
 void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t stream);
 // Name of the dominant kernel of the last launch configuration (for rocprof matching).

@@ -27,22 +27,57 @@ static void set_chunks(gd::KernelArgs &a, const RenderLaunch &rl, int W, int row
 int wf_words() { return gd::WF_WORDS; }
 int wf_max_generations() { return gd::kWfMaxGen; }
 int wf_slot_count(long long num_items) {
-    long long n = num_items < (1LL << 21) ? num_items : (1LL << 21);       // 2 M slots = 0.8 GB of path state
+    long long n = num_items < (1LL << 21) ? num_items : (1LL << 21);       // 2 M slots = 0.75 GB of path state
     n = (n + gd::kBlock - 1) / gd::kBlock * gd::kBlock;
     return (int)(n < gd::kBlock ? gd::kBlock : n);
 }
+// layout of the auxiliary block: rays | hits | keys | hist | offsets | overflow stacks (all 16-byte aligned)
+namespace {
+struct WfAux { size_t rays, hits, keys, hist, offsets, blocks, ovf, total; };
+WfAux wf_aux_layout(int slots) {
+    WfAux l{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+    l.rays = take((size_t)slots * 32); l.hits = take((size_t)slots * 32); l.keys = take((size_t)slots * 8);
+    l.hist = take((size_t)gd::kWfBins * 4); l.offsets = take((size_t)gd::kWfBins * 4);
+    l.blocks = take((size_t)(slots / gd::kBlock) * 16);
+    l.ovf = take((size_t)slots * (size_t)(GDPT_BVH_MAX_DEPTH - gd::kWfLdsLevels) * 4);
+    l.total = off;
+    return l;
+}
+}
+size_t wf_aux_bytes(int slots) { return wf_aux_layout(slots).total; }
 
 // Generations are enqueued in chunks; the host reads the number of slots that still need a step one chunk behind the
 // launches (the speculative chunk behind a finished render finds nothing to do: its kernels return at once).
 static void run_wavefront(const DevSceneView &sv, const gd::KernelArgs &a, const RenderLaunch &rl, hipStream_t stream) {
-    if (!rl.wf_state || !rl.wf_live || !rl.wf_counters || !rl.wf_host || rl.wf_slots <= 0) throw std::runtime_error("launch_render: wavefront buffers missing");
+    if (!rl.wf_state || !rl.wf_live || !rl.wf_counters || !rl.wf_host || !rl.wf_aux || rl.wf_slots <= 0) throw std::runtime_error("launch_render: wavefront buffers missing");
+    static_assert(GDPT_BVH_MAX_DEPTH > gd::kWfLdsLevels, "overflow stack levels");
+    const WfAux lay = wf_aux_layout(rl.wf_slots);
+    char *aux = (char *)rl.wf_aux;
     gd::WfBuf w{};
     w.state = rl.wf_state; w.live = rl.wf_live; w.counters = rl.wf_counters; w.n = rl.wf_slots; w.gen = 0;
+    w.rays = (float4 *)(aux + lay.rays); w.hits = (float4 *)(aux + lay.hits); w.keys = (uint2 *)(aux + lay.keys);
+    w.hist = (unsigned *)(aux + lay.hist); w.offsets = (unsigned *)(aux + lay.offsets);
+    w.block_counts = (uint4 *)(aux + lay.blocks); w.totals = rl.counters;
+    w.sort = rl.wf_sort; w.tiles_x = (sv.cam.width + 15) / 16;
+    for (int k = 0; k < 3; k++) {
+        const float lo = rl.wf_bounds[k], hi = rl.wf_bounds[3 + k];
+        w.bmin[k] = lo;
+        w.cell_scale[k] = (hi > lo) ? 16.0f / (hi - lo) : 0.0f;
+    }
+    gd::WfTrace t{};
+    t.nodes4 = sv.nodes4; t.prims = sv.prims; t.spheres = sv.spheres; t.rays = w.rays; t.hits = w.hits; t.live = w.live;
+    t.ovf = (int *)(aux + lay.ovf); t.ovf_stride = (unsigned)rl.wf_slots; t.counters = rl.counters;
+    t.num_tris = sv.num_tris; t.num_nodes4 = sv.num_nodes4; t.num_spheres = sv.num_spheres; t.search_frac = a.thresh_c; t.count_stats = a.count;
     auto ckh = [](hipError_t e, const char *what) { if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e)); };
     ckh(hipMemsetAsync(rl.wf_counters, 0, sizeof(unsigned) * 3 * gd::kWfMaxGen, stream), "hipMemsetAsync(wavefront counters)");
+    ckh(hipMemsetAsync(w.hist, 0, sizeof(unsigned) * gd::kWfBins, stream), "hipMemsetAsync(wavefront histogram)");
     launch_wf_init(w, stream);
-    // trace kernel: persistent, kWfTraceWaves waves per SIMD
-    const unsigned trace_blocks = (unsigned)rl.num_cus * (unsigned)gd::kWfTraceWaves;
+    // The trace grid covers the slots that can still hold a ray: all of them until the host has seen a generation with
+    // fewer active slots (from then on the work queue is empty and the number only falls). The kernel strides over the
+    // queue, so a grid that is too small would still be correct.
+    unsigned active_bound = (unsigned)rl.wf_slots;
     const int chunk = 8;
     int gen = 0;
     auto enqueue_chunk = [&]() {
@@ -50,7 +85,9 @@ static void run_wavefront(const DevSceneView &sv, const gd::KernelArgs &a, const
             if (gen >= gd::kWfMaxGen) throw std::runtime_error("launch_render: wavefront generation limit reached");
             w.gen = gen;
             if (rl.lambert_only) launch_wf_step_lambert(sv, a, w, stream); else launch_wf_step_general(sv, a, w, stream);
-            launch_wf_trace(sv, a, w, trace_blocks, stream);
+            launch_wf_sort(w, stream);
+            t.count = rl.wf_counters + gen;
+            launch_wf_trace(t, sv.num_spheres > 0, (active_bound + gd::kWfTraceBlock - 1) / gd::kWfTraceBlock, stream);
         }
     };
     enqueue_chunk();
@@ -61,6 +98,7 @@ static void run_wavefront(const DevSceneView &sv, const gd::KernelArgs &a, const
         if (room) enqueue_chunk();
         ckh(hipEventSynchronize(rl.wf_event), "hipEventSynchronize");
         if (*rl.wf_host == 0u) break;
+        if (*rl.wf_host < active_bound) active_bound = *rl.wf_host;
         if (!room) throw std::runtime_error("launch_render: wavefront generation limit reached");
     }
 }

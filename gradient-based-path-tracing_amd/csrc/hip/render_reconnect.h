@@ -26,57 +26,13 @@ namespace gd {
 
 struct ShiftV1 { Vertex v; D3 dir_view; bool ok; };
 
-// Lambert-only scenes inline the three-line lobe; everything else goes through the full material switch.
-// GDPT_RECONNECT_OUTLINE (diagnostic build only, `make outline-diag` + tests/diag_reconnect_outline.py) makes the switch
-// two out-of-line functions instead: 264 instead of 1103 spilled VGPRs, but 3152 instead of 1728 bytes of scratch per
-// lane (the caller parks everything live across the calls) and arguments handed over as generic pointers into the
-// caller's scratch; DESIGN.md 4.4 records what that build does on the device.
-#if defined(GDPT_RECONNECT_OUTLINE) && GDPT_RECONNECT_OUTLINE == 1
-#define GDPT_MAT_CALL __device__ __noinline__      // by-reference arguments: generic pointers into the caller's scratch
-#else
-#define GDPT_MAT_CALL GD
-#endif
-
-// Out-of-line material switch with a register ABI (GDPT_RECONNECT_OUTLINE == 2): everything the lobes read travels BY
-// VALUE — the vertex, the directions, the random numbers, the three pointers into HBM tables — and the result comes
-// back by value, so no generic pointer into private memory is ever formed.
-struct MatSampleOut { D3 dir_out; double eta, roughness; int ok; };
-struct MatEvalOut { D3 f; double pdf; };
-__device__ __noinline__ MatSampleOut mat_sample_call(const DevImage *images, const double *texels, const GdptMaterial *mat, Vertex v, D3 in, D2 ruv, double rw) {
-    DevSceneView lsv; lsv.images = images; lsv.texels = texels;      // the only scene fields a texture lookup touches
-    BsdfSample bs; bs.dir_out = splat(0); bs.eta = 0; bs.roughness = 0;
-    MatSampleOut o;
-    o.ok = bsdf_sample<true, true>(lsv, *mat, in, v, ruv, rw, bs) ? 1 : 0;
-    o.dir_out = bs.dir_out; o.eta = bs.eta; o.roughness = bs.roughness;
-    return o;
-}
-__device__ __noinline__ MatEvalOut mat_eval_call(const DevImage *images, const double *texels, const GdptMaterial *mat, Vertex v, D3 in, D3 out) {
-    DevSceneView lsv; lsv.images = images; lsv.texels = texels;
-    MatEvalOut o;
-    o.f = bsdf_eval<true, true>(lsv, *mat, in, out, v);
-    o.pdf = bsdf_pdf<true, true>(lsv, *mat, in, out, v);
-    return o;
-}
-
+// Lambert-only scenes inline the three-line lobe; everything else goes through the full material switch (inlined at each
+// of the eight call sites: DESIGN.md 4.4 records why the switch is not an out-of-line function on this toolchain).
 template <bool LAMBERT> struct Mat {
-    static GDPT_MAT_CALL bool sample(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D2 ruv, double rw, BsdfSample &s) {
-#if defined(GDPT_RECONNECT_OUTLINE) && GDPT_RECONNECT_OUTLINE == 2
-        if (!LAMBERT) {
-            const MatSampleOut o = mat_sample_call(sv.images, sv.texels, tx.materials + v.material_id, v, in, ruv, rw);
-            s.dir_out = o.dir_out; s.eta = o.eta; s.roughness = o.roughness;
-            return o.ok != 0;
-        }
-#endif
+    static GD bool sample(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D2 ruv, double rw, BsdfSample &s) {
         return mat_sample<LAMBERT, true, true>(sv, tx, v, in, ruv, rw, s);
     }
-    static GDPT_MAT_CALL void eval_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D3 out, D3 &f, double &pdf) {
-#if defined(GDPT_RECONNECT_OUTLINE) && GDPT_RECONNECT_OUTLINE == 2
-        if (!LAMBERT) {
-            const MatEvalOut o = mat_eval_call(sv.images, sv.texels, tx.materials + v.material_id, v, in, out);
-            f = o.f; pdf = o.pdf;
-            return;
-        }
-#endif
+    static GD void eval_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D3 out, D3 &f, double &pdf) {
         mat_eval_pdf<LAMBERT, true, true>(sv, tx, v, in, out, f, pdf);
     }
 };

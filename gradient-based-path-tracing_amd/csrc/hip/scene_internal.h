@@ -39,7 +39,9 @@ struct GdptScene {
     unsigned long long *d_queue = nullptr;
     // wavefront pipeline (render_wavefront.h): path state, live list, generation counters
     unsigned long long *d_wf_state = nullptr; unsigned *d_wf_live = nullptr, *d_wf_counters = nullptr, *h_wf_word = nullptr;
+    void *d_wf_aux = nullptr;      // ray / hit records, sort keys and histogram, overflow stacks (render_kernels.hip: wf_aux_layout)
     int wf_slots = 0;
+    float bounds[6] = {0, 0, 0, 0, 0, 0};   // fp32 scene bounds (min xyz, max xyz), as get_intersection_epsilon sees them
     hipEvent_t wf_event = nullptr;
     int num_cus = 256;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -63,6 +65,7 @@ struct GdptScene {
         if (d_queue) hipFree(d_queue);
         if (d_wf_state) hipFree(d_wf_state);
         if (d_wf_live) hipFree(d_wf_live);
+        if (d_wf_aux) hipFree(d_wf_aux);
         if (d_wf_counters) hipFree(d_wf_counters);
         if (h_wf_word) hipHostFree(h_wf_word);
         if (wf_event) hipEventDestroy(wf_event);

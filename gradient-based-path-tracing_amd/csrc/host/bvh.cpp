@@ -340,10 +340,10 @@ std::vector<DevBvh8Node> collapse_bvh8(const std::vector<DevBvhNode> &nodes, int
     return out;
 }
 
-WideBvh collapse_for_traversal(const std::vector<DevBvhNode> &nodes) {
+WideBvh collapse_for_traversal(const std::vector<DevBvhNode> &nodes, bool with_bvh8) {
     WideBvh w;
     w.nodes = collapse_bvh4(nodes, 4, GDPT_BVH_MAX_DEPTH, &w.stack_need);
-    w.nodes8 = collapse_bvh8(nodes, GDPT_BVH_MAX_DEPTH + GDPT_STACK_OVERFLOW, &w.stack_need8);
+    if (with_bvh8) w.nodes8 = collapse_bvh8(nodes, GDPT_BVH_MAX_DEPTH + GDPT_STACK_OVERFLOW, &w.stack_need8);
     for (const DevBvh4Node &n : w.nodes) {
         int cnt = 0;
         for (int c = 0; c < 4; c++) cnt += (n.child[c] != GDPT_CHILD_EMPTY);

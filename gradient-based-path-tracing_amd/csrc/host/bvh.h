@@ -31,7 +31,8 @@ std::vector<DevBvh8Node> collapse_bvh8(const std::vector<DevBvhNode> &nodes, int
 
 // The wide trees the device walks (stack bounds <= GDPT_BVH_MAX_DEPTH slots); arity = widest BVH4 node present.
 struct WideBvh { std::vector<DevBvh4Node> nodes; std::vector<DevBvh8Node> nodes8; int arity = 0, stack_need = 0, stack_need8 = 0; };
-WideBvh collapse_for_traversal(const std::vector<DevBvhNode> &nodes);
+// with_bvh8: also the quantised 8-wide form (the host check and the GDPT_HBM_BVH8 A/B build; product uploads do not need it)
+WideBvh collapse_for_traversal(const std::vector<DevBvhNode> &nodes, bool with_bvh8);
 
 } // namespace gdpt
 

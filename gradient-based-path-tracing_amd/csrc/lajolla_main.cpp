@@ -117,7 +117,7 @@ int main(int argc, char *argv[]) {
         int rc;
         if (sharded) {
             rc = gdpt_multi_gradient_path_render(mscene, &p, alpha, image.data(), nullptr, nullptr, nullptr, nullptr, nullptr, &rs, &ms);
-            ps.solve_ms = ms.solve_ms; ps.solver = GDPT_SOLVER_DCT;
+            ps.solve_ms = ms.solve_ms; ps.solver = GDPT_SOLVER_DEFAULT;
         } else if (desc->integrator == GDPT_INTEGRATOR_PATH) rc = gdpt_path_render(scene, &p, image.data(), &rs);
         else rc = gdpt_gradient_path_render(scene, &p, alpha, image.data(), nullptr, nullptr, nullptr, nullptr, nullptr, &rs, &ps);
         if (rc != 0) {

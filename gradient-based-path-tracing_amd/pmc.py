@@ -23,6 +23,8 @@ SQ_FLOPS = ("SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 S
 TCC_HITS = "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"
 DEFAULT_GROUPS = ("FETCH_SIZE", "WRITE_SIZE", SQ_TIME, SQ_FLOPS)
 
+NUM_SIMDS = 1024                    # 256 CUs x 4
+NUM_SHADER_ENGINES = 32
 VECTOR_FP64_PEAK_TFLOPS = 78.6      # MI355X vector fp64
 HBM_PEAK_GBS = 8000.0               # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -58,12 +60,19 @@ def _run(pmc, child_argv, outdir, timeout):
 
 
 def kernel_times(outdir):
-    """{kernel: {"calls": n, "avg_us": t}} from a --kernel-trace pass."""
+    """{kernel: {"calls": n, "avg_us": t, "first_us": t0}} from a --kernel-trace pass. avg_us is the STEADY-STATE average: a
+    kernel's first launch of the process (code-object load, cold caches and TLBs) is left out when there are others."""
     per = defaultdict(list)
     for f in glob.glob(os.path.join(outdir, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            per[_short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    return {k: {"calls": len(v), "avg_us": sum(v) / len(v)} for k, v in per.items()}
+            per[_short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    out = {}
+    for k, v in per.items():
+        v.sort()
+        d = [x[1] for x in v]
+        steady = d[1:] if len(d) > 1 else d
+        out[k] = {"calls": len(d), "avg_us": sum(steady) / len(steady), "first_us": d[0]}
+    return out
 
 
 def counter_means(outdir):
@@ -125,6 +134,13 @@ def valu_summary(c, launch_us):
     out = {}
     if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_THREAD_CYCLES_VALU"):
         out["lane_util"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+    if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_BUSY_CYCLES"):
+        # SQ_BUSY_CYCLES: shader clocks a shader engine was busy, summed over the 32 engines = 32 x the launch in clocks;
+        # SQ_ACTIVE_INST_VALU: quad-cycles (4 clocks) in which a wave had a vector instruction executing, summed over waves;
+        # two waves of a SIMD never overlap there, so the quotient is the share of the launch the 1024 vector pipes were busy
+        out["valu_busy"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (NUM_SIMDS * c["SQ_BUSY_CYCLES"] / NUM_SHADER_ENGINES)
+        if "lane_util" in out:
+            out["issue_slot_frac"] = out["valu_busy"] * out["lane_util"]     # lane-issue slots of the launch that carried a live lane
     if c.get("SQ_WAVE_CYCLES"):
         wc = c["SQ_WAVE_CYCLES"]
         for key, name in (("SQ_ACTIVE_INST_VALU", "valu_share"), ("SQ_WAIT_ANY", "wait_share"),

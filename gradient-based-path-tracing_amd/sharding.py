@@ -9,7 +9,7 @@ ranks. The exchange step of the path sits between the render 
   * halo_then_gather (what bench.py uses): with row bands cx = cx0(x,y) + cx1(x-1,y) is band-local and
     cy = cy0(x,y) + cy1(x,y-1) needs only the last cy1 row of the band above (src/render.cpp:345-349), so each rank
     receives that one row from its predecessor (W*24 bytes, point to point), assembles c, cx, cy for its own band,
-    and ONE packed all-gather moves the three assembled images (3/5 of the bytes, 1 collective instead of 5).
+    and the three assembled images are all-gathered in place (3/5 of the bytes, no packing).
 Backend-agnostic: works with torch.distributed over RCCL ("nccl") on GPUs and over gloo on CPU tensors (tests).
 """
 
@@ -105,9 +105,14 @@ def halo_exchange_cy1(dist, cy1, height, world, rank):
 
 
 def gather_packed(dist, images, height, world, rank, scratch=None):
-    """In-place all-gather of several HxWx3 images whose rows [r0,r1) are valid on this rank, as ONE collective when
-    the bands are equal (falls back to gather_bands per image otherwise). `scratch`: optional dict reused across calls
-    for the packed send/receive buffers."""
+    """In-place all-gather of several HxWx3 images whose rows [r0,r1) are valid on this rank.
+
+    Equal bands: bands are contiguous row ranges in rank order, so a rank's band already sits at its final offset
+    rank * band_elems of the flat image and every image gathers IN PLACE, as the C host does (csrc/hip/multi_gpu.hip:
+    grouped in-place ncclAllGather) — no packing and no copies; the collectives of the images are issued together and
+    waited for together. Ragged bands fall back to gather_bands per image. When the wire is not the tensors' own device
+    (gloo rehearsal over device tensors) the bands are packed into ONE host buffer and ONE collective instead; `scratch`
+    is an optional dict reused across calls for those buffers."""
     if world == 1:
         return images
     if not equal_bands(height, world):
@@ -117,8 +122,16 @@ def gather_packed(dist, images, height, world, rank, scratch=None):
     r0, r1 = band_rows(height, world, rank)
     n = len(images)
     band_elems = (r1 - r0) * images[0].shape[1] * images[0].shape[2]
-    scratch = {} if scratch is None else scratch
     wire = wire_device(dist, images[0])
+    if wire == images[0].device:
+        works = []
+        for im in images:
+            flat = im.view(-1)
+            works.append(dist.all_gather_into_tensor(flat, flat[rank * band_elems:(rank + 1) * band_elems], async_op=True))
+        for wk in works:
+            wk.wait()
+        return images
+    scratch = {} if scratch is None else scratch
     key = (n, band_elems, images[0].dtype, wire)
     if scratch.get("key") != key:
         scratch["key"] = key
@@ -136,7 +149,7 @@ def gather_packed(dist, images, height, world, rank, scratch=None):
 class ShardedGradPath:
     """One rank's view of the sharded hot path — the step bench.py times and the gloo tests drive:
 
-        render own band -> last cy1 row to the band below -> assemble own band -> ONE packed all-gather of c, cx, cy
+        render own band -> last cy1 row to the band below -> assemble own band -> in-place all-gather of c, cx, cy
         -> global screened-Poisson solve (replicated on every rank)
 
     The class owns the order of those phases and the exchange between ranks (halo_exchange_cy1, gather_packed); what a
@@ -171,7 +184,7 @@ class ShardedGradPath:
             halo_exchange_cy1(self.dist, self.bufs["cy1"], self.height, self.world, self.rank)
         if r1 > r0:
             self.assemble(self.bufs, (self.c, self.cx, self.cy), self.rows)
-        if self.world > 1:            # exchange 2: ONE packed all-gather of the assembled bands
+        if self.world > 1:            # exchange 2: the assembled bands, gathered in place
             gather_packed(self.dist, [self.c, self.cx, self.cy], self.height, self.world, self.rank, self._scratch)
         self.phase_hook("exchange")
         pstats = self.solve(self.c, self.cx, self.cy, self.out, want_stats)

@@ -189,6 +189,7 @@ typedef struct GdptPoissonStats {
  * DCT_MFMA: the same solve with the passes as hand-written fp64 MFMA GEMM kernels whose epilogues carry the spectral
  *     division, the DC override and the final scaling (5 launches instead of 8; 0.13 ms at 512x512 — DESIGN.md 4.2). */
 enum { GDPT_SOLVER_CG = 0, GDPT_SOLVER_DCT = 1, GDPT_SOLVER_DCT_MFMA = 2 };
+#define GDPT_SOLVER_DEFAULT GDPT_SOLVER_DCT   /* what gdpt_poisson_solve, gdpt_gradient_path_render and gdpt_multi_* use */
 
 typedef struct GdptScene GdptScene;   /* opaque: device-resident scene (BVH2 + BVH4, triangles, materials, textures) */
 
@@ -255,6 +256,10 @@ int gdpt_poisson_solve_device(int width, int height,
                               int solver, double tol, int max_iters,
                               void *stream, GdptPoissonStats *stats /* nullable */);
 
+/* Drops the solver scratch the library keeps for `stream` on the current device (buffers, handles, events). Owners of a
+ * stream call it before destroying the stream, with no solve in flight on it; a stream the library never saw is fine. */
+int gdpt_poisson_forget_stream(void *stream);
+
 /* Whole Integrator::GradPath: render -> assemble -> solve -> final image (host, W*H*3 doubles).
  * Optionally returns the five raw buffers too (any of them may be NULL). */
 int gdpt_gradient_path_render(GdptScene *scene, const GdptRenderParams *params, double dataCost,
@@ -272,7 +277,10 @@ int gdpt_gradient_path_render(GdptScene *scene, const GdptRenderParams *params, 
 #define GDPT_MULTI_MAX_DEVICES 16
 /* Transport of the halo row and the all-gather.
  *   GDPT_EXCHANGE_RCCL:      ncclSend/ncclRecv + grouped in-place ncclAllGather (ncclBroadcast per band when the bands are
- *                            ragged) on one communicator per device; devices must be distinct.
+ *                            ragged) on one communicator per device; devices must be distinct. NOT YET RUN BETWEEN TWO
+ *                            DEVICES (every box this library was developed on had one GPU): correct by construction
+ *                            and by the one-device tests only. A failure behind the first collective aborts the
+ *                            communicators (ncclCommAbort) and spends the handle: create a new one.
  *   GDPT_EXCHANGE_PEER_COPY: direct device-to-device copies (hipMemcpyPeerAsync over xGMI, ordered by events): every device
  *                            pushes its band to every other one, N-1 links at once. Accepts a device twice. */
 enum { GDPT_EXCHANGE_RCCL = 0, GDPT_EXCHANGE_PEER_COPY = 1 };

@@ -37,7 +37,11 @@ class OracleStats(C.Structure):
 
 
 def build(force=False):
-    """Compile liboracle.so with the host compiler if it is missing (seconds)."""
+    """Compile liboracle.so with the host compiler if it is missing (seconds). GDPT_ORACLE_SO names another build of the
+    same source instead (bench.py's cpu_baseline leg times one compiled with -O3 -march=native on the box it runs on)."""
+    alt = os.environ.get("GDPT_ORACLE_SO")
+    if alt and os.path.exists(alt):
+        return alt
     so = os.path.join(_HERE, "liboracle.so")
     if force or not os.path.exists(so):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)

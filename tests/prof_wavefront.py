@@ -19,17 +19,21 @@ for name, xml, film, integ, spp in cases:
     sd = G.parse_scene(xml, film=film)
     sc = G.Scene(sd)
     res = {}
-    for mode in (0, 1):
-        with G.debug_knobs(wavefront=mode):
+    modes = [("lane machine", dict(wavefront=0)), ("wavefront unsorted", dict(wavefront=1, wf_sort=0)),
+             ("wavefront octant-major", dict(wavefront=1, wf_sort=1)), ("wavefront cell-major", dict(wavefront=1, wf_sort=2))]
+    if os.environ.get("WF_ONLY"):
+        modes = [m for m in modes if m[0].endswith(os.environ["WF_ONLY"])]
+    for label, knobs in modes:
+        with G.debug_knobs(**knobs):
             best = 1e9
             for _ in range(3):
                 bufs, st = sc.render(spp, G.RNG_SAMPLE)
                 best = min(best, st.render_ms)
-        res[mode] = (bufs, st, best)
-    same = all(np.array_equal(res[0][0][k], res[1][0][k], equal_nan=True) for k in res[0][0])
-    a, b = res[0], res[1]
-    print(f"{name}: lane machine {a[2]:.2f} ms ({a[1].samples / a[2] / 1e3:.0f} Msamples/s) | wavefront {b[2]:.2f} ms ({b[1].samples / b[2] / 1e3:.0f} Msamples/s) | "
-          f"identical {same} | rays {a[1].rays} {b[1].rays} bounces {a[1].bounces} {b[1].bounces}", flush=True)
-    if not same:
-        for k in res[0][0]:
-            d = np.abs(res[0][0][k] - res[1][0][k]); print("   ", k, "max abs diff", np.nanmax(d), "differing px", int((d > 0).any(axis=2).sum()))
+        res[label] = (bufs, st, best)
+    ref = res[modes[0][0]]
+    for label, (bufs, st, best) in res.items():
+        same = all(np.array_equal(ref[0][k], bufs[k], equal_nan=True) for k in bufs)
+        print(f"{name}: {label:24s} {best:8.2f} ms ({st.samples / best / 1e3:6.0f} Msamples/s, {st.rays / best / 1e6:5.2f} Grays/s) | identical {same} | rays {st.rays} bounces {st.bounces}", flush=True)
+        if not same:
+            for k in bufs:
+                d = np.abs(ref[0][k] - bufs[k]); print("   ", k, "max abs diff", np.nanmax(d), "differing px", int((d > 0).any(axis=2).sum()))

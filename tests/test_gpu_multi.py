@@ -53,6 +53,28 @@ def test_multi_device_set_equals_single_device(G, scene_tmp, devices, exchange, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("band", [0, 1, 2])
+@pytest.mark.parametrize("stage", [1, 2, 3, 4])
+def test_a_band_that_fails_does_not_hang_the_others(G, scene_tmp, band, stage):
+    """A device that fails in any stage of a call (render, halo + assembly, all-gather, solve) must not leave the other
+    bands waiting for it: every rank arrives at the agreed checkpoint behind the stage, the verdict is formed inside the
+    barrier, all stand down together, the call reports the band that failed — and the handle still works afterwards
+    (peer-copy transport: nothing is torn down; with RCCL the communicators would be aborted and the handle refused).
+    The failure is injected by the test knobs multi_fail_band / multi_fail_stage (csrc/hip/multi_gpu.hip: rank_body)."""
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=48, height=80)
+    sd = G.parse_scene(xml)
+    want_out, _, _, _ = G.Scene(sd).gradient_path_render(3, G.RNG_SAMPLE, return_buffers=True)
+    ms = G.MultiScene(sd, (0, 0, 0), exchange=G.EXCHANGE_PEER_COPY)
+    if stage == 4 and band != 0:
+        pytest.skip("the solve runs on the first device only")
+    with G.debug_knobs(multi_fail_band=band, multi_fail_stage=stage):
+        with pytest.raises(G.GdptError, match=rf"band {band}\): injected failure \(stage {stage}\)"):
+            ms.gradient_path_render(3, G.RNG_SAMPLE)
+    out, _, _, _ = ms.gradient_path_render(3, G.RNG_SAMPLE, return_buffers=True)
+    assert np.array_equal(out, want_out)
+
+
+@pytest.mark.gpu
 def test_multi_rejects_bad_device_sets(G, scene_tmp):
     sd = G.parse_scene(scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=32, height=32))
     with pytest.raises(G.GdptError, match="visible"):

@@ -314,7 +314,8 @@ def test_kernel_without_sphere_and_texture_code_equals_the_general_one(G, scene_
                                                    ("sponza/sponza.xml", None, (33, 17), 3), ("sponza/sponza.xml", None, (640, 360), 24)])
 def test_wavefront_pipeline_equals_the_lane_machine(G, O, scene_tmp, rel, integ, film, spp):
     """Scenes walked from HBM can run as a wavefront pipeline (render_wavefront.h: a step kernel over path slots whose state
-    lives in HBM + a persistent trace kernel, one generation per ray) instead of the lane machine. Same per-sample program,
+    lives in HBM, a counting sort of the generation's rays by (octant, origin cell), and a trace kernel of <= 64 VGPRs at 8 waves
+    per SIMD, one generation per ray) instead of the lane machine. Same per-sample program,
     same streams, same per-item summation order: the five buffers must be bit-identical, counters included, and equal
     the oracle."""
     xml = scene_variant(scene_tmp, rel, width=film[0], height=film[1], integrator=integ)
@@ -327,6 +328,12 @@ def test_wavefront_pipeline_equals_the_lane_machine(G, O, scene_tmp, rel, integ,
         band, bs = sc.render(spp, G.RNG_SAMPLE, rows=(16, 48) if film[1] >= 48 else (0, 16))
     with G.debug_knobs(wavefront=1, wf_slots=max(512, film[0] * film[1] // 4)):        # far fewer slots than work items: every slot runs many items in turn
         few, fs = sc.render(spp, G.RNG_SAMPLE)
+    for sort in (0, 2):                           # the ray queue in slot order / sorted cell-major (the default above: octant-major):
+        with G.debug_knobs(wavefront=1, wf_sort=sort):       # which lane walks which ray cannot change a hit
+            other, os_ = sc.render(spp, G.RNG_SAMPLE)
+        for k in BUFS:
+            assert np.array_equal(lane[k], other[k]), (k, sort)
+        assert (os_.rays, os_.bounces) == (ls.rays, ls.bounces)
     for k in BUFS:
         assert np.array_equal(lane[k], few[k]), k
     assert (fs.rays, fs.bounces) == (ls.rays, ls.bounces)
