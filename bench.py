@@ -77,6 +77,12 @@ def parse_args(argv=None):
                     help="nccl = RCCL (the measured configuration). gloo = rehearsal of the N>1 step where fewer than N GPUs "
                          "exist: ranks share the visible devices and the exchange is staged through host memory; the line "
                          "is marked \"rehearsal\" and is not a measurement")
+    ap.add_argument("--bands", choices=("cost", "equal"), default="cost",
+                    help="N>1: 'cost' = row bands of equal measured cost (a 1-spp pilot counts the rays of every tile row; exact "
+                         "counts, so every rank cuts the same bands), 'equal' = equal tile-row counts")
+    ap.add_argument("--plan-bands", type=int, default=0,
+                    help="cut every pixel's samples into work items as for this many row bands (default: --gpus); a 1-GPU run with "
+                         "--plan-bands N produces the N-GPU run's images bit for bit (GdptRenderParams.plan_rows)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # internal: workload under rocprofv3
     return ap.parse_args(argv)
 
@@ -207,10 +213,19 @@ def run_rank(args):
     ptr = lambda t: t.data_ptr()
     scene_rel = os.path.relpath(os.path.abspath(args.scene), ROOT)
 
+    # work items are cut for the largest band of the sharding (the same on every rank): GdptRenderParams.plan_rows
+    plan_bands = args.plan_bands if args.plan_bands > 0 else world
+    tile_costs = scene.tile_row_costs() if args.bands == "cost" and max(world, plan_bands) > 1 else None
+
+    def cut(n):
+        return sharding.bands_weighted(H, n, tile_costs) if tile_costs is not None and n > 1 else sharding.all_bands(H, n)
+    bands = cut(world)
+    plan_rows = max(b[1] - b[0] for b in cut(plan_bands))
+
     def make_pipeline(spp_total, hook=None):
         def render_band(bufs, rows, want_stats):
             return scene.render_device([ptr(bufs[k]) for k in names], spp=spp_total, rng_scheme=G.RNG_SAMPLE, rows=rows,
-                                       stream=stream, want_stats=want_stats, shift=shift)
+                                       stream=stream, want_stats=want_stats, shift=shift, plan_rows=plan_rows)
 
         def assemble(bufs, dst, rows):
             G.assemble_device(W, H, [ptr(bufs[k]) for k in names], [ptr(t) for t in dst], stream=stream, rows=rows)
@@ -219,7 +234,7 @@ def run_rank(args):
             return G.poisson_solve_device(W, H, ptr(c), ptr(cx), ptr(cy), ptr(out), alpha=args.alpha, stream=stream, want_stats=want_stats)
 
         return sharding.ShardedGradPath(dist, world, rank, H, lambda: torch.zeros((H, W, 3), dtype=torch.float64, device=dev),
-                                        render_band, assemble, solve, phase_hook=hook)
+                                        render_band, assemble, solve, phase_hook=hook, bands=bands)
 
     def fence():
         if world > 1:
@@ -284,7 +299,7 @@ def run_rank(args):
     import ctypes as C
     cs = G.GdptRenderStats()
     cs.nodes_visited = 2 ** 64 - 1            # request flag understood by gdpt_render_device
-    p = G._params(spp_total, G.RNG_SAMPLE, (r0, r1), shift=shift)
+    p = G._params(spp_total, G.RNG_SAMPLE, (r0, r1), shift=shift, plan_rows=plan_rows)
     G._check(G.lib().gdpt_render_device(scene.handle, C.byref(p), *[C.c_void_p(ptr(pipe.bufs[k])) for k in names],
                                         C.c_void_p(stream), C.byref(cs)))
 
@@ -299,7 +314,7 @@ def run_rank(args):
 
         def make2(sc, st_):
             def render_band(bufs, rows, want_stats):
-                return sc.render_device([ptr(bufs[k]) for k in names], spp=spp_total, rng_scheme=G.RNG_SAMPLE, rows=rows, stream=st_, want_stats=False, shift=shift)
+                return sc.render_device([ptr(bufs[k]) for k in names], spp=spp_total, rng_scheme=G.RNG_SAMPLE, rows=rows, stream=st_, want_stats=False, shift=shift, plan_rows=plan_rows)
 
             def assemble(bufs, dst, rows):
                 G.assemble_device(W, H, [ptr(bufs[k]) for k in names], [ptr(t) for t in dst], stream=st_, rows=rows)
@@ -353,7 +368,8 @@ def run_rank(args):
                                f"({spp_total} spp total), render+assemble+Poisson(DCT-I as fp64 GEMM) per step"
                                + (" [shift=reconnect: extension mode, NOT the headline workload]" if args.shift == "reconnect" else ""),
                    "rng": "sample-stream PCG32",
-                   "sharding": f"{world} row bands, 1-row halo + in-place all-gather of c,cx,cy ({args.dist_backend})" if world > 1 else "single GPU",
+                   "sharding": (f"{world} row bands ({'equal measured cost: rows ' + ' '.join(str(b[1] - b[0]) for b in bands) if tile_costs is not None else 'equal tile-row counts'}), "
+                                f"1-row halo + in-place all-gather / per-band broadcast of c,cx,cy ({args.dist_backend})") if world > 1 else "single GPU",
                    "alpha": args.alpha},
         "render_ms": render_ms, "exchange_ms": ph["exchange"], "poisson_ms": ph["solve"],
         "render_msamples_per_s": W * (r1 - r0) * spp_total / render_ms / 1e3 if render_ms > 0 else 0.0,

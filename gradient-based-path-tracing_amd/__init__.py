@@ -70,6 +70,8 @@ def lib():
         L.gdpt_bvh_check.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int32)]
         L.gdpt_assemble_rows_device.argtypes = [C.c_int] * 4 + [vp] * 9
         L.gdpt_band_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.gdpt_band_rows_weighted.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.gdpt_tile_row_costs.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.c_int]
         L.gdpt_multi_create.argtypes = [C.POINTER(defs.GdptSceneDesc), C.POINTER(defs.GdptMultiConfig), C.POINTER(vp)]
         L.gdpt_multi_free.argtypes = [vp]
         L.gdpt_multi_free.restype = None
@@ -131,9 +133,10 @@ def parse_scene(filename, film=(0, 0)):
     return SceneDesc(p)
 
 
-def _params(spp, rng_scheme, rows, max_depth_override=0, shift=0):
+def _params(spp, rng_scheme, rows, max_depth_override=0, shift=0, plan_rows=0):
     p = defs.GdptRenderParams()
     p.shift_mode = int(shift)
+    p.plan_rows = int(plan_rows)
     p.spp, p.rng_scheme = int(spp), int(rng_scheme)
     p.row_begin, p.row_end = int(rows[0]), int(rows[1])
     p.max_depth_override = int(max_depth_override)
@@ -156,22 +159,23 @@ class Scene:
         _check(lib().gdpt_scene_info(self.handle, *[C.byref(x) for x in v]))
         return dict(zip(("num_nodes", "num_tris", "num_spheres", "bvh_depth"), [x.value for x in v]))
 
-    def render(self, spp=0, rng_scheme=defs.RNG_SAMPLE, rows=(0, 0), shift=defs.SHIFT_REFERENCE):
+    def render(self, spp=0, rng_scheme=defs.RNG_SAMPLE, rows=(0, 0), shift=defs.SHIFT_REFERENCE, plan_rows=0):
         """Five-buffer render to host arrays (HxWx3 float64). Returns (buffers, GdptRenderStats).
-        `shift`: SHIFT_REFERENCE (the reference's offsets) or SHIFT_RECONNECT (include/gdpt.h)."""
+        `shift`: SHIFT_REFERENCE (the reference's offsets) or SHIFT_RECONNECT (include/gdpt.h).
+        `plan_rows`: GdptRenderParams.plan_rows (0 = work items cut for the whole film)."""
         shape = (self.height, self.width, 3)
         bufs = {k: np.zeros(shape, dtype=np.float64) for k in ("img", "cx0", "cy0", "cx1", "cy1")}
         st = defs.GdptRenderStats()
-        p = _params(spp, rng_scheme, rows, shift=shift)
+        p = _params(spp, rng_scheme, rows, shift=shift, plan_rows=plan_rows)
         _check(lib().gdpt_render(self.handle, C.byref(p), _dp(bufs["img"]), _dp(bufs["cx0"]), _dp(bufs["cy0"]),
                                  _dp(bufs["cx1"]), _dp(bufs["cy1"]), C.byref(st)))
         return bufs, st
 
     def render_device(self, ptrs, spp=0, rng_scheme=defs.RNG_SAMPLE, rows=(0, 0), stream=None, want_stats=False,
-                      shift=defs.SHIFT_REFERENCE):
+                      shift=defs.SHIFT_REFERENCE, plan_rows=0):
         """Five-buffer render into device memory; `ptrs` = 5 device addresses (e.g. torch tensor.data_ptr())."""
         st = defs.GdptRenderStats() if want_stats else None
-        p = _params(spp, rng_scheme, rows, shift=shift)
+        p = _params(spp, rng_scheme, rows, shift=shift, plan_rows=plan_rows)
         _check(lib().gdpt_render_device(self.handle, C.byref(p), *[C.c_void_p(int(x)) for x in ptrs],
                                         C.c_void_p(int(stream) if stream else 0), C.byref(st) if st is not None else None))
         return st
@@ -191,17 +195,24 @@ class Scene:
         _check(lib().gdpt_path_render_device(self.handle, C.byref(p), C.c_void_p(int(ptr)), C.c_void_p(int(stream) if stream else 0), None))
 
     def gradient_path_render(self, spp=0, rng_scheme=defs.RNG_SAMPLE, alpha=0.04, return_buffers=False,
-                             shift=defs.SHIFT_REFERENCE):
+                             shift=defs.SHIFT_REFERENCE, plan_rows=0):
         """Whole Integrator::GradPath: render + assembly + screened-Poisson solve (src/render.cpp:257-370)."""
         shape = (self.height, self.width, 3)
         out = np.zeros(shape, dtype=np.float64)
         bufs = {k: np.zeros(shape, dtype=np.float64) for k in ("img", "cx0", "cy0", "cx1", "cy1")}
         rs, ps = defs.GdptRenderStats(), defs.GdptPoissonStats()
-        p = _params(spp, rng_scheme, (0, 0), shift=shift)
+        p = _params(spp, rng_scheme, (0, 0), shift=shift, plan_rows=plan_rows)
         _check(lib().gdpt_gradient_path_render(self.handle, C.byref(p), float(alpha), _dp(out),
                                                _dp(bufs["img"]), _dp(bufs["cx0"]), _dp(bufs["cy0"]), _dp(bufs["cx1"]), _dp(bufs["cy1"]),
                                                C.byref(rs), C.byref(ps)))
         return (out, bufs, rs, ps) if return_buffers else out
+
+    def tile_row_costs(self, spp=1):
+        """Rays of a pilot render of every 16-pixel tile row (gdpt_tile_row_costs): what sharding.bands_weighted balances by."""
+        T = (self.height + 15) // 16
+        buf = (C.c_double * T)()
+        _check(lib().gdpt_tile_row_costs(self.handle, int(spp), buf, T))
+        return [float(x) for x in buf]
 
     def close(self):
         if getattr(self, "handle", None):
@@ -241,15 +252,23 @@ def band_rows(height, num_bands, band):
     return r0.value, r1.value
 
 
+def band_rows_weighted(height, num_bands, band, costs):
+    """Rows [r0, r1) of one band of a cost-balanced sharding, as the C host computes them (gdpt_band_rows_weighted)."""
+    r0, r1 = C.c_int32(), C.c_int32()
+    arr = (C.c_double * len(costs))(*[float(c) for c in costs])
+    _check(lib().gdpt_band_rows_weighted(int(height), int(num_bands), int(band), arr, len(costs), C.byref(r0), C.byref(r1)))
+    return r0.value, r1.value
+
+
 class MultiScene:
     """The scene uploaded to several devices of one node, tile loop sharded into row bands (include/gdpt.h,
     gdpt_multi_*): replaces the reference's thread pool over tiles (src/parallel.cpp:183-256)."""
 
-    def __init__(self, scene_desc, devices, exchange=defs.EXCHANGE_RCCL):
+    def __init__(self, scene_desc, devices, exchange=defs.EXCHANGE_RCCL, balance=False):
         self.desc = scene_desc
         self.width, self.height = scene_desc.width, scene_desc.height
         cfg = defs.GdptMultiConfig()
-        cfg.num_devices, cfg.exchange = len(devices), int(exchange)
+        cfg.num_devices, cfg.exchange, cfg.balance = len(devices), int(exchange), int(bool(balance))
         for i, d in enumerate(devices):
             cfg.devices[i] = int(d)
         h = C.c_void_p()

@@ -67,7 +67,7 @@ class GdptSceneDesc(C.Structure):
 
 class GdptRenderParams(C.Structure):
     _fields_ = [("spp", C.c_int32), ("rng_scheme", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32),
-                ("max_depth_override", C.c_int32), ("shift_mode", C.c_int32)]
+                ("max_depth_override", C.c_int32), ("shift_mode", C.c_int32), ("plan_rows", C.c_int32), ("reserved", C.c_int32)]
 
 
 class GdptRenderStats(C.Structure):
@@ -86,7 +86,8 @@ EXCHANGE_RCCL, EXCHANGE_PEER_COPY = 0, 1
 
 
 class GdptMultiConfig(C.Structure):
-    _fields_ = [("num_devices", C.c_int32), ("exchange", C.c_int32), ("devices", C.c_int32 * GDPT_MULTI_MAX_DEVICES)]
+    _fields_ = [("num_devices", C.c_int32), ("exchange", C.c_int32), ("devices", C.c_int32 * GDPT_MULTI_MAX_DEVICES),
+                ("balance", C.c_int32), ("reserved", C.c_int32)]
 
 
 class GdptMultiStats(C.Structure):

@@ -56,6 +56,22 @@ struct DevBvh8Node {
     int32_t pad[6];
 };
 
+// BVH4 node with quantised child boxes, 64 B, 64-B aligned: the SAME tree as DevBvh4Node (node i here is node i there, same
+// child references), each bound one byte on the node's own grid `org[axis] + q * scale[axis]`, lower bounds rounded down and
+// upper bounds up (verified in double on the host), so a grid box contains the fp32 box it replaces. A lane fetches a node
+// with four 16-byte loads instead of seven: the walk of a scene that lives in HBM is bound by the number of per-lane
+// requests the texture-address unit has to serialise, not by bytes.
+struct DevBvh4QNode {
+    float org[3];
+    float scale[3];
+    uint8_t qlo[3][4];   // qlo[axis][child]
+    uint8_t qhi[3][4];
+    int32_t child[4];
+};
+#ifndef GDPT_HBM_Q4
+#define GDPT_HBM_Q4 0              // 1: scenes walked from HBM use DevBvh4QNode
+#endif
+
 // Traversal record of one primitive, 48 B, in BVH leaf order.
 // Triangle: v0, e1 = fl(v1-v0), e2 = fl(v2-v0) in fp32; gid = global triangle id (index into DevTriShade).
 // Sphere:   gid = GDPT_SPHERE_FLAG | sphere index; the fp32 fields are unused (fp64 data in DevSphere).
@@ -125,6 +141,7 @@ struct DevSceneView {
     const DevBvhNode *nodes;
     const DevBvh4Node *nodes4;              // wide form of the same tree (LDS-resident scenes)
     const DevBvh8Node *nodes8;              // 8-wide quantised form (scenes walked from HBM)
+    const DevBvh4QNode *nodes4q;            // nodes4 with quantised boxes (scenes walked from HBM, GDPT_HBM_Q4 builds)
     const DevPrim *prims;
     const DevTriShade *tris;
     const DevSphere *spheres;

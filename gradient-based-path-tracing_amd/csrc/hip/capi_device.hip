@@ -276,6 +276,7 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
     v.nodes = sc->keep(upload(bvh.nodes));
     v.nodes4 = sc->keep(upload(nodes4));
     v.nodes8 = sc->keep(upload(wide.nodes8));
+    v.nodes4q = GDPT_HBM_Q4 ? sc->keep(upload(gdpt::quantise_bvh4(nodes4))) : nullptr;
     v.prims = sc->keep(upload(prims));
     v.tris = sc->keep(upload(tris));
     v.spheres = sc->keep(upload(spheres));
@@ -387,7 +388,7 @@ namespace {
 
 using gdpt::build_scene;
 
-struct Band { int spp, rng, row_begin, row_end, max_depth, shift; };
+struct Band { int spp, rng, row_begin, row_end, max_depth, shift, plan_rows; };
 
 Band resolve(const GdptScene *sc, const GdptRenderParams *p) {
     if (!sc) throw std::runtime_error("null scene handle");
@@ -405,6 +406,8 @@ Band resolve(const GdptScene *sc, const GdptRenderParams *p) {
     if (b.rng == GDPT_RNG_TILE && ((b.row_begin % 16) != 0 || ((b.row_end % 16) != 0 && b.row_end != sc->view.cam.height)))
         throw std::runtime_error("gdpt_render: GDPT_RNG_TILE bands must cover whole 16-pixel tile rows");
     b.max_depth = (p && p->max_depth_override != 0) ? p->max_depth_override : sc->view.max_depth;
+    b.plan_rows = (p && p->plan_rows > 0) ? std::min(p->plan_rows, sc->view.cam.height) : sc->view.cam.height;
+    if (p && p->plan_rows < 0) throw std::runtime_error("gdpt_render: plan_rows must be >= 0");
     return b;
 }
 
@@ -421,7 +424,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     if (b.spp <= 0) throw std::runtime_error("gdpt_render: samples per pixel must be > 0");
     if (!img || !cx0 || !cy0 || !cx1 || !cy1) throw std::runtime_error("gdpt_render: null output buffer");
     gdpt::RenderLaunch rl{};
-    rl.spp = b.spp; rl.rng_scheme = b.rng; rl.row_begin = b.row_begin; rl.row_end = b.row_end; rl.max_depth = b.max_depth; rl.shift_mode = b.shift;
+    rl.spp = b.spp; rl.rng_scheme = b.rng; rl.row_begin = b.row_begin; rl.row_end = b.row_end; rl.max_depth = b.max_depth; rl.shift_mode = b.shift; rl.plan_rows = b.plan_rows;
     rl.img = img; rl.cx0 = cx0; rl.cy0 = cy0; rl.cx1 = cx1; rl.cy1 = cy1;
     rl.counters = sc->d_counters;
     rl.count_traversal = stats && stats->nodes_visited == ~0ull;   // request flag: caller presets nodes_visited = UINT64_MAX
@@ -443,7 +446,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.blocks_per_cu = env_int("blocks_per_cu", 0);
     rl.stamped = env_int("stamps", 0) != 0;
     {
-        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, sc->view.cam.height, b.spp, rl.force_log2k, (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256);
+        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, b.plan_rows, b.spp, rl.force_log2k, (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256);
         if (need > sc->partials_doubles) {
             if (sc->d_partials) { ck(hipStreamSynchronize(stream), "hipStreamSynchronize"); hipFree(sc->d_partials); sc->d_partials = nullptr; }
             ck(hipMalloc((void **)&sc->d_partials, need * sizeof(double)), "hipMalloc(work-item partials)");
@@ -456,7 +459,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.two_sided_machine = !sc->one_sided && !sc->has_rough && !rl.force_eager && b.rng == GDPT_RNG_SAMPLE && !env_int("no_twosided_machine", 0);
     if (rl.two_sided_machine) {
         const long long tiles = (long long)((sc->view.cam.width + 15) / 16) * ((b.row_end - b.row_begin + 15) / 16);
-        const long long items = (tiles * 256) * gdpt::make_chunk_plan(b.spp, rl.force_log2k, (long long)sc->view.cam.width * sc->view.cam.height,
+        const long long items = (tiles * 256) * gdpt::make_chunk_plan(b.spp, rl.force_log2k, (long long)sc->view.cam.width * b.plan_rows,
                                                                       (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256).n;
         const size_t need = gdpt::twosided_log_bytes(gdpt::persistent_blocks(rl, items));
         if (need > sc->bounce_log_bytes) {
@@ -471,7 +474,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
                    b.rng == GDPT_RNG_SAMPLE && b.shift == GDPT_SHIFT_REFERENCE;
     if (rl.wavefront) {
         const long long tiles = (long long)((sc->view.cam.width + 15) / 16) * ((b.row_end - b.row_begin + 15) / 16);
-        const long long items = (tiles * 256) * gdpt::make_chunk_plan(b.spp, rl.force_log2k, (long long)sc->view.cam.width * sc->view.cam.height,
+        const long long items = (tiles * 256) * gdpt::make_chunk_plan(b.spp, rl.force_log2k, (long long)sc->view.cam.width * b.plan_rows,
                                                                       (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256).n;
         int slots = gdpt::wf_slot_count(items);
         { const int forced = env_int("wf_slots", 0); if (forced > 0) slots = std::min(slots, (forced + 255) / 256 * 256); }   // tests: force slot reuse
@@ -535,7 +538,7 @@ void path_render_device_impl(GdptScene *sc, const GdptRenderParams *params, doub
     if (b.spp <= 0) throw std::runtime_error("gdpt_path_render: samples per pixel must be > 0");
     if (!img) throw std::runtime_error("gdpt_path_render: null output buffer");
     gdpt::RenderLaunch rl{};
-    rl.spp = b.spp; rl.rng_scheme = b.rng; rl.row_begin = b.row_begin; rl.row_end = b.row_end; rl.max_depth = b.max_depth; rl.shift_mode = b.shift;
+    rl.spp = b.spp; rl.rng_scheme = b.rng; rl.row_begin = b.row_begin; rl.row_end = b.row_end; rl.max_depth = b.max_depth; rl.shift_mode = b.shift; rl.plan_rows = b.plan_rows;
     rl.img = img;
     rl.counters = sc->d_counters;
     rl.count_traversal = stats && stats->nodes_visited == ~0ull;
@@ -549,7 +552,7 @@ void path_render_device_impl(GdptScene *sc, const GdptRenderParams *params, doub
     rl.scene_fits_lds = !env_int("no_lds_scene", 0) &&
                         gdpt::scene_fits_lds_wide(sc->view.num_nodes4, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->view.num_lights, sc->wide_stack_need);
     {
-        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, sc->view.cam.height, b.spp, rl.force_log2k, (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256);
+        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, b.plan_rows, b.spp, rl.force_log2k, (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256);
         if (need > sc->partials_doubles) {
             if (sc->d_partials) { ck(hipStreamSynchronize(stream), "hipStreamSynchronize"); hipFree(sc->d_partials); sc->d_partials = nullptr; }
             ck(hipMalloc((void **)&sc->d_partials, need * sizeof(double)), "hipMalloc(work-item partials)");
@@ -644,6 +647,23 @@ int gdpt_render(GdptScene *scene, const GdptRenderParams *params,
         render_device_impl(scene, params, scene->scene_spp, scene->d_buf[0], scene->d_buf[1], scene->d_buf[2], scene->d_buf[3], scene->d_buf[4],
                            nullptr, stats ? stats : &local);
         for (int k = 0; k < 5; k++) ck(hipMemcpy(host[k], scene->d_buf[k], elems * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
+    });
+}
+
+int gdpt_tile_row_costs(GdptScene *scene, int spp, double *cost, int capacity) {
+    return gdpt::guarded([&]() {
+        if (!scene || !cost) throw std::runtime_error("gdpt_tile_row_costs: null argument");
+        const int H = scene->view.cam.height, T = (H + 15) / 16;
+        if (capacity < T) throw std::runtime_error("gdpt_tile_row_costs: capacity < ceil(height / 16)");
+        ck(hipSetDevice(scene->device), "hipSetDevice");
+        scene->ensure_buffers((size_t)scene->view.cam.width * H * 3);
+        for (int t = 0; t < T; t++) {       // one small launch per tile row; the counters are exact, so is the cost
+            GdptRenderParams p{};
+            p.spp = spp > 0 ? spp : 1; p.rng_scheme = GDPT_RNG_SAMPLE; p.row_begin = t * 16; p.row_end = std::min(H, t * 16 + 16);
+            GdptRenderStats st{};
+            render_device_impl(scene, &p, scene->scene_spp, scene->d_buf[0], scene->d_buf[1], scene->d_buf[2], scene->d_buf[3], scene->d_buf[4], nullptr, &st);
+            cost[t] = (double)st.rays;
+        }
     });
 }
 

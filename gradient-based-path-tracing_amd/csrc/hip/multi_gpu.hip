@@ -57,6 +57,38 @@ void band_rows(int height, int n, int b, int *r0, int *r1) {
     *r1 = std::min(t1 * kTile, height);
 }
 
+// Bands of whole tile rows whose largest COST is as small as a contiguous split allows (linear partition, dynamic
+// programme over (bands, tile rows); ties go to the split found first, so every caller gets the same bands). cost[t] > 0 is
+// the measured cost of tile row t (gdpt_tile_row_costs: rays of a pilot render). With fewer tile rows than bands the last
+// bands stay empty, as in band_rows. Mirror: sharding.band_rows_weighted.
+void band_rows_weighted(int height, int n, const double *cost, int tile_rows, std::vector<int> *first_tile) {
+    const int T = (height + kTile - 1) / kTile;
+    if (tile_rows != T) throw std::runtime_error("band_rows_weighted: one cost per 16-pixel tile row expected");
+    first_tile->assign((size_t)n + 1, T);
+    const int used = std::min(n, T);                  // bands that own rows
+    std::vector<double> pre((size_t)T + 1, 0.0);
+    for (int t = 0; t < T; t++) {
+        if (!(cost[t] >= 0.0)) throw std::runtime_error("band_rows_weighted: negative or non-finite cost");
+        pre[(size_t)t + 1] = pre[(size_t)t] + cost[t];
+    }
+    const double inf = 1e300;
+    // best[k][t]: smallest possible largest-band cost when the first t tile rows form k bands (each with >= 1 tile row)
+    std::vector<std::vector<double>> best((size_t)used + 1, std::vector<double>((size_t)T + 1, inf));
+    std::vector<std::vector<int>> cut((size_t)used + 1, std::vector<int>((size_t)T + 1, 0));
+    best[0][0] = 0.0;
+    for (int k = 1; k <= used; k++)
+        for (int t = k; t <= T - (used - k); t++)
+            for (int s = k - 1; s < t; s++) {
+                if (best[(size_t)k - 1][(size_t)s] >= inf) continue;
+                const double v = std::max(best[(size_t)k - 1][(size_t)s], pre[(size_t)t] - pre[(size_t)s]);
+                if (v < best[(size_t)k][(size_t)t]) { best[(size_t)k][(size_t)t] = v; cut[(size_t)k][(size_t)t] = s; }
+            }
+    int t = T;
+    for (int k = used; k >= 1; k--) { (*first_tile)[(size_t)k] = t; t = cut[(size_t)k][(size_t)t]; }
+    (*first_tile)[0] = 0;
+    for (int k = used + 1; k <= n; k++) (*first_tile)[(size_t)k] = T;
+}
+
 // Reusable barrier for the per-device host threads of one call (C++17: no std::barrier). Every arrival carries the
 // rank's own verdict ("I have failed"); the verdict of the ROUND — has anyone? — is formed under the barrier's lock by the
 // last arriver and handed to every participant, so all ranks take the same branch behind it. (Reading the other ranks'
@@ -96,6 +128,7 @@ namespace { struct Job { const GdptRenderParams *params = nullptr; double alpha 
 struct GdptMulti {
     int n = 0, w = 0, h = 0, exchange = GDPT_EXCHANGE_RCCL, scene_spp = 0;
     bool equal_bands = false;
+    int plan_rows = 0;             // rows of the largest band: GdptRenderParams::plan_rows of every band's render
     bool comms_aborted = false;    // a failure behind the first collective tore the communicators down: the handle is spent
     std::vector<Rank> ranks;
     // one host thread per device 1..n-1, started once and parked between calls (device 0 is driven by the caller, as
@@ -158,6 +191,7 @@ void rank_body(GdptMulti *m, int i, const GdptRenderParams *params, double alpha
         if (owns) {
             GdptRenderParams p = params ? *params : GdptRenderParams{};
             p.row_begin = me.row_begin; p.row_end = me.row_end;
+            if (p.plan_rows == 0) p.plan_rows = m->plan_rows;          // work items cut for the largest band, the same on every device
             if (me.row_begin == 0 && me.row_end == 0) throw std::runtime_error("empty band");   // (0,0) would mean "whole image"
             gdpt::render_device_impl(me.scene.get(), &p, m->scene_spp, me.buf[0], me.buf[1], me.buf[2], me.buf[3], me.buf[4], me.stream, nullptr);
         }
@@ -280,6 +314,15 @@ int gdpt_band_rows(int height, int num_bands, int band, int32_t *row_begin, int3
     });
 }
 
+int gdpt_band_rows_weighted(int height, int num_bands, int band, const double *tile_row_cost, int num_tile_rows, int32_t *row_begin, int32_t *row_end) {
+    return gdpt::guarded([&]() {
+        if (height <= 0 || num_bands <= 0 || band < 0 || band >= num_bands || !row_begin || !row_end || !tile_row_cost) throw std::runtime_error("gdpt_band_rows_weighted: bad argument");
+        std::vector<int> first;
+        band_rows_weighted(height, num_bands, tile_row_cost, num_tile_rows, &first);
+        *row_begin = std::min(first[(size_t)band] * kTile, height); *row_end = std::min(first[(size_t)band + 1] * kTile, height);
+    });
+}
+
 int gdpt_multi_create(const GdptSceneDesc *desc, const GdptMultiConfig *cfg, GdptMulti **out) {
     return gdpt::guarded([&]() {
         if (!desc || !cfg || !out) throw std::runtime_error("gdpt_multi_create: null argument");
@@ -302,14 +345,24 @@ int gdpt_multi_create(const GdptSceneDesc *desc, const GdptMultiConfig *cfg, Gdp
         m->ranks.resize((size_t)n);
         const size_t elems = (size_t)m->w * m->h * 3;
         bool equal = true;
+        std::vector<int> first_tile;                 // cfg->balance: bands by the measured cost of their tile rows
         for (int i = 0; i < n; i++) {
             Rank &r = m->ranks[(size_t)i];
             r.device = cfg->devices[i];
-            band_rows(m->h, n, i, &r.row_begin, &r.row_end);
+            if (cfg->balance && n > 1 && i > 0) {
+                r.row_begin = std::min(first_tile[(size_t)i] * kTile, m->h); r.row_end = std::min(first_tile[(size_t)i + 1] * kTile, m->h);
+            } else band_rows(m->h, n, i, &r.row_begin, &r.row_end);
             if (r.row_end - r.row_begin != m->ranks[0].row_end - m->ranks[0].row_begin || r.row_end <= r.row_begin) equal = false;
             r.scene.reset(new GdptScene());
             gdpt::build_scene(desc, r.device, r.scene.get());       // sets the device
             r.scene->scene_spp = desc->samples_per_pixel;
+            if (cfg->balance && n > 1 && i == 0) {    // pilot on the first device: rays per tile row at 1 spp (exact counts: every caller sees the same bands)
+                const int T = (m->h + kTile - 1) / kTile;
+                std::vector<double> cost((size_t)T);
+                if (gdpt_tile_row_costs(r.scene.get(), 1, cost.data(), T) != 0) throw std::runtime_error(std::string("gdpt_multi_create: pilot render: ") + gdpt_last_error());
+                band_rows_weighted(m->h, n, cost.data(), T, &first_tile);
+                r.row_begin = 0; r.row_end = std::min(first_tile[1] * kTile, m->h);
+            }
             ck(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking), "hipStreamCreate");
             for (double *&b : r.buf) { ck(hipMalloc((void **)&b, elems * sizeof(double)), "hipMalloc(band images)"); ck(hipMemset(b, 0, elems * sizeof(double)), "hipMemset"); }
             for (hipEvent_t &e : r.ev_t) ck(hipEventCreate(&e), "hipEventCreate");
@@ -317,6 +370,7 @@ int gdpt_multi_create(const GdptSceneDesc *desc, const GdptMultiConfig *cfg, Gdp
             ck(hipEventCreateWithFlags(&r.ev_pushed, hipEventDisableTiming), "hipEventCreate");
         }
         m->equal_bands = equal;
+        for (const Rank &r : m->ranks) m->plan_rows = std::max(m->plan_rows, r.row_end - r.row_begin);
         if (cfg->exchange == GDPT_EXCHANGE_PEER_COPY) {
             for (int i = 0; i < n; i++)
                 for (int j = 0; j < n; j++) {

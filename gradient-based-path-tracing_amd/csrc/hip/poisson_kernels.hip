@@ -264,75 +264,96 @@ __global__ __launch_bounds__(kBlock) void dct_finalize_kernel(Geo g, const doubl
 
 
 // ------------------------------------------------------------------------------------------------
-// The 1-D transforms as hand-written fp64 MFMA GEMMs (v_mfma_f64_16x16x4_f64), epilogues fused.
-//   C[M x N] = A[M x K] * B[K x N], row-major, one matrix per channel (blockIdx.z; the transform matrix has stride 0).
-// Block = 4 waves, block tile 64 x 64, K step 16 staged through LDS, double-buffered: while the MFMAs of step s run, the
-// global loads of step s+1 are in flight and land in the other LDS buffer. Both operands sit k-major in LDS
-// ([k][m] and [k][n], row stride 80 doubles = 160 dwords, so the four k rows a wave reads at once fall on different bank
-// halves: conflict-free ds_read_b64); a wave owns a 32 x 32 quadrant = 2 x 2 MFMA tiles. Operand lanes: A[row l&15][k l>>4],
-// B[k l>>4][col l&15]; result register r of lane l is C[(l>>4) + 4r][l&15] (the f64 map, not the f32 one).
-// Epilogues (EPI): 0 plain; 1 the spectral division  F^ = H^ / (alpha - (float)(lapY[y] + lapX[x]))  with the DC override
-// F^[0,0] = sum(w u) (src/render.cpp:229-239: the block holding element (0,0) reduces the per-block partials of
-// dct_rhs_kernel itself); 2 the final  out[(y*W+x)*3+ch] = f / (4 (W-1)(H-1))  (:245-247), planar -> interleaved.
-constexpr int kGemmBM = 64, kGemmBN = 64, kGemmBK = 16, kGemmLdB = 80, kGemmLdA = 18;
+// The 1-D transforms as hand-written fp64 MFMA GEMMs (v_mfma_f64_16x16x4_f64) on HALF the flops: the DCT-I matrix is
+// even / odd symmetric about its middle column, cos(pi j (n-1-k)/(n-1)) = (-1)^j cos(pi j k/(n-1)) with w_{n-1-k} = w_k, so
+//     Y[2q+p] = sum_{x < ceil(n/2)} E_p[x][q] * (X[x] + (-1)^p X[n-1-x]),   E_p[x][q] = w_x cos(pi x (2q+p)/(n-1))
+// (the middle sample of an odd n pairs with itself: it counts once for p = 0 and not at all for p = 1). Each 1-D pass is
+// two products of half the depth and half the outputs, one per parity p of the output index, and the fold rides on the
+// operand staging: the thread that brings X[x] to LDS also fetches X[n-1-x] and stores the sum or the difference. Outputs go
+// straight to rows / columns 2q+p of the natural layout, so the next pass sees an ordinary matrix.
+//   FORM 0 (row pass,    T = X * Cw):    C[m][2q+p] = sum_x (X[m][x] +- X[m][K-1-x]) * E_p[x][q]      data operand = A, folded along its rows
+//   FORM 1 (column pass, Y = Ch^T * T):  C[2q+p][n] = sum_y E_p^T[q][y] * (X[y][n] +- X[K-1-y][n])    data operand = B, folded along its columns
+// Block = 8 waves (two per SIMD: one wave's LDS traffic and waits sit under the other's MFMAs), block tile 64 x 64 of one
+// (channel, parity) pair in blockIdx.z, K step 16 staged through LDS, double-buffered: while the MFMAs of step s run, the
+// global loads of step s+1 are in flight and land in the other buffer. LDS images: A tile row-major [64][18] (the MFMA's A
+// lanes read [row l&15][k l>>4]: 36 m + 2 k dwords, conflict-free within each half wave), B tile k-major [16][80]
+// ([k l>>4][col l&15]: the two k rows of a half wave sit 32 banks apart). A wave owns 16 x 32 = two MFMA tiles; result
+// register r of lane l is C[(l>>4) + 4r][l&15] (the f64 map, not the f32 one).
+// Epilogues (EPI, column pass only): 0 plain; 1 the spectral division  F^ = H^ / (alpha - (float)(lapY[y] + lapX[x]))  with
+// the DC override F^[0,0] = sum(w u) (src/render.cpp:229-239: the block holding element (0,0) reduces the per-block partials
+// of dct_rhs_kernel itself); 2 the final  out[(y*W+x)*3+ch] = f / (4 (W-1)(H-1))  (:245-247), planar -> interleaved.
+// (History, whole 512x512x3 solve on MI355X: unfolded 64x64 tiles with 4 waves 132 us, rocBLAS dgemm_strided_batched 103 us.)
+constexpr int kGemmBM = 64, kGemmBN = 64, kGemmBK = 16, kGemmLdB = 80, kGemmLdA = 18, kGemmThreads = 512;
 struct GemmEpi {
     double alpha; const double *lap_x, *lap_y;      // EPI 1
     const double *dc_partials; int dc_nb;            // EPI 1: [3][dc_nb] block partials of sum(w u)
     double denom; double *out; int out_w;            // EPI 2
 };
-// Block tile 64 x 64, K step 16, double-buffered, two blocks per CU. LDS images: A tile row-major [64][18] (the MFMA's A
-// lanes read [row l&15][k l>>4]: 36 m + 2 k dwords, conflict-free within each half wave), B tile k-major [16][80]
-// ([k l>>4][col l&15]: the two k rows of a half wave sit 32 banks apart). A wave owns a 32 x 32 quadrant = 2 x 2 MFMA tiles.
-// (Tried and measured on MI355X, whole 512x512x3 solve: 32 x 64 tiles with K step 32: 129 us; 64 x 64 with K step 32:
-// 135 us; this form: 132 us at 512^2 and the best of the three at 1024^2, 544 us — against 103 / 486 us with rocBLAS's
-// MT128x64 / MT32x64 macro-tiles, which run the 1024^2 products at 65-75 TFLOP/s, i.e. within 20 % of the fp64 MFMA peak.)
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void dct_gemm_f64(int M, int N, int K, const double *A, int lda, long long strideA,
-                                                       const double *B, int ldb, long long strideB, double *C, int ldc, long long strideC, GemmEpi e) {
+// M x N = extent of the output; K = length of the folded dimension (FORM 0: K == N, FORM 1: K == M); X = data operand with
+// row stride ldx and channel stride strideX; E0 / E1 = the parity tables (FORM 0: E_p, ceil(K/2) x ceil-or-floor(K/2);
+// FORM 1: E_p^T), row stride ldE each.
+template <int FORM, int EPI>
+__global__ __launch_bounds__(kGemmThreads, 2) void dct_fold_gemm_f64(int M, int N, int K, const double *X, int ldx, long long strideX,
+                                                                     const double *E0, const double *E1, int ldE,
+                                                                     double *C, int ldc, long long strideC, GemmEpi e) {
     typedef double d4 __attribute__((ext_vector_type(4)));
     typedef double d2 __attribute__((ext_vector_type(2)));
     __shared__ __attribute__((aligned(16))) double sA[2][kGemmBM * kGemmLdA];
     __shared__ __attribute__((aligned(16))) double sB[2][kGemmBK * kGemmLdB];
     __shared__ double red[kBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ch = blockIdx.z;
-    A += (long long)ch * strideA; B += (long long)ch * strideB; C += (long long)ch * strideC;
+    const int ch = blockIdx.z >> 1, p = blockIdx.z & 1;
+    X += (long long)ch * strideX; C += (long long)ch * strideC;
+    const double *E = p ? E1 : E0;
+    const int Kf = (K + 1) >> 1;                         // folded depth
+    const int mid = (K & 1) ? (K >> 1) : -1;             // the self-paired sample of an odd length
+    const int Qn = (K + 1 - p) >> 1;                     // outputs of this parity along the folded dimension
+    const int Mt = FORM == 0 ? M : Qn, Nt = FORM == 0 ? Qn : N;     // extent of this block's (parity-compact) output index space
     const int m0 = blockIdx.y * kGemmBM, n0 = blockIdx.x * kGemmBN;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    // staging roles: A tile 64 x 16 -> thread (row tid >> 2, 4 consecutive k: four threads read one 128-byte line);
-    // B tile 16 x 64 -> thread (k = tid >> 4, 4 consecutive n)
-    const int am = tid >> 2, ak = (tid & 3) * 4;
-    const int bk = tid >> 4, bn = (tid & 15) * 4;
+    if (m0 >= Mt || n0 >= Nt) return;                    // (block-uniform: the odd parity has one output less)
+    const int wm = (wave >> 1) * 16, wn = (wave & 1) * 32;
+    // staging roles: A tile 64 x 16 -> thread (row tid >> 3, 2 consecutive k); B tile 16 x 64 -> thread (k = tid >> 5, 2 consecutive n)
+    const int am = tid >> 3, ak = (tid & 7) * 2;
+    const int bk = tid >> 5, bn = (tid & 31) * 2;
+    const double sgn = p ? -1.0 : 1.0;
     // vector loads when every 16-byte pair is aligned and the tile lies inside the matrices (block-uniform)
-    const bool fast = ((lda | ldb) & 1) == 0 && m0 + kGemmBM <= M && n0 + kGemmBN <= N &&
-                      ((reinterpret_cast<unsigned long long>(A) | reinterpret_cast<unsigned long long>(B)) & 15ull) == 0;
-    d2 ra[2], rb[2];
+    const bool fast = ((ldx | ldE | K) & 1) == 0 && m0 + kGemmBM <= Mt && n0 + kGemmBN <= Nt &&
+                      ((reinterpret_cast<unsigned long long>(X) | reinterpret_cast<unsigned long long>(E)) & 15ull) == 0;
+    d2 ra, rb;
+    auto fold = [&](double a, double b, int x) { return (x == mid) ? (p ? 0.0 : a) : a + sgn * b; };
     auto fetch = [&](int k0) {
-        if (fast && k0 + kGemmBK <= K) {
-            const d2 *pa = reinterpret_cast<const d2 *>(A + (long long)(m0 + am) * lda + k0 + ak);
-            const d2 *pb = reinterpret_cast<const d2 *>(B + (long long)(k0 + bk) * ldb + n0 + bn);
-            ra[0] = pa[0]; ra[1] = pa[1]; rb[0] = pb[0]; rb[1] = pb[1];
+        if (fast && k0 + kGemmBK <= Kf) {                 // (K even here: no middle sample)
+            if (FORM == 0) {
+                const double *row = X + (long long)(m0 + am) * ldx;
+                const d2 a = *reinterpret_cast<const d2 *>(row + k0 + ak), b = *reinterpret_cast<const d2 *>(row + K - 2 - (k0 + ak));   // b = (X[K-2-x], X[K-1-x])
+                ra = d2{a.x + sgn * b.y, a.y + sgn * b.x};
+                rb = *reinterpret_cast<const d2 *>(E + (long long)(k0 + bk) * ldE + n0 + bn);
+            } else {
+                ra = *reinterpret_cast<const d2 *>(E + (long long)(m0 + am) * ldE + k0 + ak);
+                const d2 a = *reinterpret_cast<const d2 *>(X + (long long)(k0 + bk) * ldx + n0 + bn), b = *reinterpret_cast<const d2 *>(X + (long long)(K - 1 - (k0 + bk)) * ldx + n0 + bn);
+                rb = d2{a.x + sgn * b.x, a.y + sgn * b.y};
+            }
             return;
         }
-        const int gm = m0 + am, gk = k0 + bk;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int ka = k0 + ak + j, gn = n0 + bn + j;
-            ra[j >> 1][j & 1] = (gm < M && ka < K) ? A[(long long)gm * lda + ka] : 0.0;
-            rb[j >> 1][j & 1] = (gk < K && gn < N) ? B[(long long)gk * ldb + gn] : 0.0;
+        for (int j = 0; j < 2; j++) {
+            const int gm = m0 + am, ka = k0 + ak + j, gk = k0 + bk, gn = n0 + bn + j;
+            if (FORM == 0) {
+                ra[j] = (gm < Mt && ka < Kf) ? fold(X[(long long)gm * ldx + ka], X[(long long)gm * ldx + (K - 1 - ka)], ka) : 0.0;
+                rb[j] = (gk < Kf && gn < Nt) ? E[(long long)gk * ldE + gn] : 0.0;
+            } else {
+                ra[j] = (gm < Mt && ka < Kf) ? E[(long long)gm * ldE + ka] : 0.0;
+                rb[j] = (gk < Kf && gn < Nt) ? fold(X[(long long)gk * ldx + gn], X[(long long)(K - 1 - gk) * ldx + gn], gk) : 0.0;
+            }
         }
     };
     auto stage = [&](int buf) {
-        d2 *qa = reinterpret_cast<d2 *>(&sA[buf][am * kGemmLdA + ak]);     // 144 am + 32 (tid & 3) bytes: 16-byte aligned
-        d2 *qb = reinterpret_cast<d2 *>(&sB[buf][bk * kGemmLdB + bn]);
-        qa[0] = ra[0]; qa[1] = ra[1]; qb[0] = rb[0]; qb[1] = rb[1];
+        *reinterpret_cast<d2 *>(&sA[buf][am * kGemmLdA + ak]) = ra;      // 144 am + 16 (tid & 7) bytes: 16-byte aligned
+        *reinterpret_cast<d2 *>(&sB[buf][bk * kGemmLdB + bn]) = rb;
     };
-    d4 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-    const int steps = (K + kGemmBK - 1) / kGemmBK;
+    d4 acc[2];
+    acc[0] = d4{0.0, 0.0, 0.0, 0.0}; acc[1] = d4{0.0, 0.0, 0.0, 0.0};
+    const int steps = (Kf + kGemmBK - 1) / kGemmBK;
     fetch(0);
     stage(0);
     __syncthreads();
@@ -341,41 +362,49 @@ __global__ __launch_bounds__(256, 2) void dct_gemm_f64(int M, int N, int K, cons
         if (s + 1 < steps) fetch((s + 1) * kGemmBK);               // in flight during the MFMAs below
         const double *pa = sA[buf] + (wm + (lane & 15)) * kGemmLdA + (lane >> 4);
         const double *pb = sB[buf] + (lane >> 4) * kGemmLdB + wn + (lane & 15);
-        double a0[kGemmBK / 4], a1[kGemmBK / 4], b0[kGemmBK / 4], b1[kGemmBK / 4];
+        double a[kGemmBK / 4], b0[kGemmBK / 4], b1[kGemmBK / 4];
 #pragma unroll
         for (int ks = 0; ks < kGemmBK / 4; ks++) {                 // all operand reads of the step first: one LDS latency, not four
-            a0[ks] = pa[ks * 4]; a1[ks] = pa[ks * 4 + 16 * kGemmLdA];
+            a[ks] = pa[ks * 4];
             b0[ks] = pb[ks * 4 * kGemmLdB]; b1[ks] = pb[ks * 4 * kGemmLdB + 16];
         }
 #pragma unroll
         for (int ks = 0; ks < kGemmBK / 4; ks++) {
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ks], b0[ks], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ks], b1[ks], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[ks], b0[ks], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[ks], b1[ks], acc[1][1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b0[ks], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b1[ks], acc[1], 0, 0, 0);
         }
         if (s + 1 < steps) stage(buf ^ 1);
         __syncthreads();
     }
     double dc = 0.0;
-    if (EPI == 1 && m0 == 0 && n0 == 0) dc = reduce_partials(e.dc_partials + (size_t)ch * e.dc_nb, e.dc_nb, red);   // block-uniform branch
+    if (EPI == 1 && p == 0 && m0 == 0 && n0 == 0) {                // block-uniform branch: this block holds element (0,0)
+        // (red[] has one slot per wave of a 256-thread block: the first four waves reduce, all eight pass the barriers)
+        double v = 0;
+        if (tid < kBlock) for (int i = tid; i < e.dc_nb; i += kBlock) v += e.dc_partials[(size_t)ch * e.dc_nb + i];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0 && wave < kBlock / 64) red[wave] = v;
+        __syncthreads();
+        dc = red[0];
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int k = 1; k < kBlock / 64; k++) dc += red[k];
+    }
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = m0 + wm + 16 * i + (lane >> 4) + 4 * r, col = n0 + wn + 16 * j + (lane & 15);
-                if (row >= M || col >= N) continue;
-                double v = acc[i][j][r];
-                if (EPI == 1) {
-                    const float resp = (float)(e.lap_y[row] + e.lap_x[col]);          // `float ftLapResponse` in the reference (:233)
-                    v = v / (e.alpha - resp);
-                    if (row == 0 && col == 0) v = dc;
-                }
-                if (EPI == 2) e.out[((size_t)row * e.out_w + col) * 3 + ch] = v / e.denom;
-                else C[(long long)row * ldc + col] = v;
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int tr = m0 + wm + (lane >> 4) + 4 * r, tc = n0 + wn + 16 * j + (lane & 15);       // parity-compact indices
+            if (tr >= Mt || tc >= Nt) continue;
+            const int row = FORM == 0 ? tr : 2 * tr + p, col = FORM == 0 ? 2 * tc + p : tc;
+            double v = acc[j][r];
+            if (EPI == 1) {
+                const float resp = (float)(e.lap_y[row] + e.lap_x[col]);          // `float ftLapResponse` in the reference (:233)
+                v = v / (e.alpha - resp);
+                if (row == 0 && col == 0) v = dc;
             }
+            if (EPI == 2) e.out[((size_t)row * e.out_w + col) * 3 + ch] = v / e.denom;
+            else C[(long long)row * ldc + col] = v;
+        }
 }
 
 } // namespace gp
@@ -426,8 +455,11 @@ namespace {
 struct DctPlan {
     int n = 0;
     double *d_mat = nullptr;   // C[j][k] = w_j cos(pi j k/(n-1)), row-major n x n
-    double *d_mat_t = nullptr; // its transpose, row-major (the column transform's left operand)
     double *d_lap = nullptr;   // 2 cos(pi i/(n-1)) (the caller adds -4 on the y axis)
+    // parity tables of the folded products (dct_fold_gemm_f64): E_p[x][q] = w_x cos(pi x (2q+p)/(n-1)), x < ceil(n/2),
+    // and their transposes; row strides padded to an even number of doubles
+    double *d_e[2] = {nullptr, nullptr}, *d_et[2] = {nullptr, nullptr};
+    int ld_e = 0, ld_et = 0;
 };
 // Transform matrices and eigenvalue tables depend on the extent only: one set per device, shared (read-only) by every
 // stream. Scratch buffers, the rocBLAS handle and the timing events belong to one (device, stream) pair, so solves on
@@ -437,7 +469,11 @@ struct DctTables {
     std::vector<std::unique_ptr<DctPlan>> plans;
     std::vector<std::pair<int, double *>> lap_y;
     void release() {
-        for (auto &p : plans) { if (p->d_mat) hipFree(p->d_mat); if (p->d_mat_t) hipFree(p->d_mat_t); if (p->d_lap) hipFree(p->d_lap); }
+        for (auto &p : plans) {
+            if (p->d_mat) hipFree(p->d_mat);
+            if (p->d_lap) hipFree(p->d_lap);
+            for (int k = 0; k < 2; k++) { if (p->d_e[k]) hipFree(p->d_e[k]); if (p->d_et[k]) hipFree(p->d_et[k]); }
+        }
         for (auto &l : lap_y) if (l.second) hipFree(l.second);
         plans.clear(); lap_y.clear();
     }
@@ -496,13 +532,26 @@ const DctPlan &get_plan(DctTables &t, int n) {
     ck(hipMalloc((void **)&p->d_mat, m.size() * sizeof(double)), "hipMalloc(dct matrix)");
     ck(hipMalloc((void **)&p->d_lap, lap.size() * sizeof(double)), "hipMalloc(dct lap)");
     ck(hipMemcpy(p->d_mat, m.data(), m.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(dct matrix)");
-    {
-        std::vector<double> mt((size_t)n * n);
-        for (int j = 0; j < n; j++) for (int k = 0; k < n; k++) mt[(size_t)k * n + j] = m[(size_t)j * n + k];
-        ck(hipMalloc((void **)&p->d_mat_t, mt.size() * sizeof(double)), "hipMalloc(dct matrix^T)");
-        ck(hipMemcpy(p->d_mat_t, mt.data(), mt.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(dct matrix^T)");
-    }
     ck(hipMemcpy(p->d_lap, lap.data(), lap.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(dct lap)");
+    {
+        const int kf = (n + 1) / 2;
+        p->ld_e = (kf + 1) & ~1; p->ld_et = (kf + 1) & ~1;       // (both parities share the wider stride)
+        for (int par = 0; par < 2; par++) {
+            const int qn = (n + 1 - par) / 2;
+            std::vector<double> e((size_t)kf * p->ld_e, 0.0), et((size_t)std::max(qn, 1) * p->ld_et, 0.0);
+            for (int x = 0; x < kf; x++) {
+                const double wx = (x > 0 && x < n - 1) ? 2.0 : 1.0;
+                for (int q = 0; q < qn; q++) {
+                    const double v = wx * ctab[((size_t)x * (size_t)(2 * q + par)) % ctab.size()];
+                    e[(size_t)x * p->ld_e + q] = v; et[(size_t)q * p->ld_et + x] = v;
+                }
+            }
+            ck(hipMalloc((void **)&p->d_e[par], e.size() * sizeof(double)), "hipMalloc(dct parity table)");
+            ck(hipMalloc((void **)&p->d_et[par], et.size() * sizeof(double)), "hipMalloc(dct parity table^T)");
+            ck(hipMemcpy(p->d_e[par], e.data(), e.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(dct parity table)");
+            ck(hipMemcpy(p->d_et[par], et.data(), et.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(dct parity table^T)");
+        }
+    }
     p->n = n;
     t.plans.push_back(std::move(p));
     return *t.plans.back();
@@ -525,14 +574,15 @@ PoissonResult poisson_dct(int dev, DctWorkspace &ws, int w, int h, const double 
         if (!ws.handle) rb(rocblas_create_handle(&ws.handle), "rocblas_create_handle");
         rb(rocblas_set_stream(ws.handle, stream), "rocblas_set_stream");
     }
-    const double *Cw, *Ch, *ChT, *lap_x, *lap_y;
+    const double *Cw, *Ch, *lap_x, *lap_y, *Ew[2], *EhT[2];
+    int ld_ew, ld_eht;
     {
         DctTables &t = device_tables(dev);
         std::lock_guard<std::mutex> lk(t.mu);
         const DctPlan &pw = get_plan(t, w);
-        Cw = pw.d_mat; lap_x = pw.d_lap;
+        Cw = pw.d_mat; lap_x = pw.d_lap; Ew[0] = pw.d_e[0]; Ew[1] = pw.d_e[1]; ld_ew = pw.ld_e;
         const DctPlan &ph = get_plan(t, h);
-        Ch = ph.d_mat; ChT = ph.d_mat_t;
+        Ch = ph.d_mat; EhT[0] = ph.d_et[0]; EhT[1] = ph.d_et[1]; ld_eht = ph.ld_et;
         lap_y = get_lap_y(t, h);
     }
     gp::Geo g{w, h, w * h * 3, w * 3};
@@ -568,17 +618,21 @@ PoissonResult poisson_dct(int dev, DctWorkspace &ws, int w, int h, const double 
         transform(A, B, A);                                  // A = DCT2D(F^)
         hipLaunchKernelGGL(gp::dct_finalize_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, A, d_out);
     } else {
-        // GDPT_SOLVER_DCT_MFMA: own fp64 MFMA GEMMs, per channel plane (h x w row-major):  T = X * Cw  (rows),  Y = Ch^T * T  (columns);
-        // spectral division + DC override ride on the second GEMM, the final scaling + interleaving on the fourth
+        // GDPT_SOLVER_DCT_MFMA: own folded fp64 MFMA GEMMs, per (channel, output parity) plane:  T = X * Cw  (rows),
+        // Y = Ch^T * T  (columns); spectral division + DC override ride on the second product, the final scaling +
+        // interleaving on the fourth
         gp::GemmEpi e{};
         e.alpha = alpha; e.lap_x = lap_x; e.lap_y = lap_y; e.dc_partials = ws.partials; e.dc_nb = nb;
         e.denom = 4.0 * (double)(w - 1) * (double)(h - 1); e.out = d_out; e.out_w = w;
-        const dim3 grid((unsigned)((w + gp::kGemmBN - 1) / gp::kGemmBN), (unsigned)((h + gp::kGemmBM - 1) / gp::kGemmBM), 3), block(256);
+        const int qw = (w + 1) / 2, qh = (h + 1) / 2;           // outputs of the even parity along the folded dimension
+        const dim3 block(gp::kGemmThreads);
+        const dim3 grid_rows((unsigned)((qw + gp::kGemmBN - 1) / gp::kGemmBN), (unsigned)((h + gp::kGemmBM - 1) / gp::kGemmBM), 6);
+        const dim3 grid_cols((unsigned)((w + gp::kGemmBN - 1) / gp::kGemmBN), (unsigned)((qh + gp::kGemmBM - 1) / gp::kGemmBM), 6);
         const long long pl = (long long)plane;
-        hipLaunchKernelGGL((gp::dct_gemm_f64<0>), grid, block, 0, stream, h, w, w, (const double *)A, w, pl, Cw, w, 0LL, B, w, pl, e);    // B = A * Cw
-        hipLaunchKernelGGL((gp::dct_gemm_f64<1>), grid, block, 0, stream, h, w, h, ChT, h, 0LL, (const double *)B, w, pl, A, w, pl, e);  // A = Ch^T * B, / (alpha - lambda), DC
-        hipLaunchKernelGGL((gp::dct_gemm_f64<0>), grid, block, 0, stream, h, w, w, (const double *)A, w, pl, Cw, w, 0LL, B, w, pl, e);    // B = A * Cw
-        hipLaunchKernelGGL((gp::dct_gemm_f64<2>), grid, block, 0, stream, h, w, h, ChT, h, 0LL, (const double *)B, w, pl, A, w, pl, e);  // out = Ch^T * B / denom
+        hipLaunchKernelGGL((gp::dct_fold_gemm_f64<0, 0>), grid_rows, block, 0, stream, h, w, w, (const double *)A, w, pl, Ew[0], Ew[1], ld_ew, B, w, pl, e);      // B = A * Cw
+        hipLaunchKernelGGL((gp::dct_fold_gemm_f64<1, 1>), grid_cols, block, 0, stream, h, w, h, (const double *)B, w, pl, EhT[0], EhT[1], ld_eht, A, w, pl, e);   // A = Ch^T * B, / (alpha - lambda), DC
+        hipLaunchKernelGGL((gp::dct_fold_gemm_f64<0, 0>), grid_rows, block, 0, stream, h, w, w, (const double *)A, w, pl, Ew[0], Ew[1], ld_ew, B, w, pl, e);      // B = A * Cw
+        hipLaunchKernelGGL((gp::dct_fold_gemm_f64<1, 2>), grid_cols, block, 0, stream, h, w, h, (const double *)B, w, pl, EhT[0], EhT[1], ld_eht, A, w, pl, e);   // out = Ch^T * B / denom
     }
     ck(hipGetLastError(), "dct kernel launch");
     float ms = 0;

@@ -159,6 +159,7 @@ struct TraceCtx {      // (every field is set by setup_trace or, for the wavefro
     const DevBvhNode *nodes;
     const DevBvh4Node *nodes4;
     const DevBvh8Node *nodes8;
+    const DevBvh4QNode *nodes4q;
     const DevPrim *prims;
     const DevTriShade *tris;
     const GdptMaterial *materials;
@@ -209,6 +210,46 @@ GD void visit_wide(const DevBvh4Node &n, const float oi[3], const float inv[3], 
         }
         const int ch = c == 0 ? c0 : (c == 1 ? c1 : (c == 2 ? c2 : c3));
         const bool h = (ch != GDPT_CHILD_EMPTY) && (t0 <= t1);   // see box_hit
+        w.key[c] = h ? ((__float_as_uint(t0) & ~3u) | (unsigned)c) : kMissKey;
+    }
+#define GDPT_CSWAP(i, j) { unsigned lo_ = min(w.key[i], w.key[j]), hi_ = max(w.key[i], w.key[j]); w.key[i] = lo_; w.key[j] = hi_; }
+    GDPT_CSWAP(0, 1) GDPT_CSWAP(2, 3) GDPT_CSWAP(0, 2) GDPT_CSWAP(1, 3) GDPT_CSWAP(1, 2)
+#undef GDPT_CSWAP
+#pragma unroll
+    for (int i = 0; i < 4; i++) w.ch[i] = pick4(w.key[i], c0, c1, c2, c3);
+}
+
+// One BVH4 node with quantised boxes (DevBvh4QNode: scenes walked from HBM, GDPT_HBM_Q4 builds): four 16-byte loads instead
+// of seven. Distances are formed as fma(q, A, B) with A = scale / d, B = (org - o) / d per axis — conservative by the
+// argument given at visit_wide8 (the grid boxes enclose the boxes the host padded). The plane a ray enters a slab through
+// is picked by the sign of d on the whole dword of four bounds (one v_cndmask per axis and side), so a child costs six
+// conversions, six fmas and a max3 / min3 pair: the instruction count of the fp32 node's ordered test.
+GD void visit_wide_q4(const DevBvh4QNode &n, const float oi[3], const float inv[3], float tnear, float tb, WideVisit &w) {
+    const uint4 *qp = (const uint4 *)&n;
+    const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
+    const float org[3] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
+    const float scale[3] = {__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
+    const unsigned lo[3] = {q1.z, q1.w, q2.x}, hi[3] = {q2.y, q2.z, q2.w};
+    const int c0 = (int)q3.x, c1 = (int)q3.y, c2 = (int)q3.z, c3 = (int)q3.w;
+    float A[3], B[3];
+    unsigned nq[3], fq[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        A[k] = scale[k] * inv[k];
+        B[k] = fmaf(org[k], inv[k], -oi[k]);
+        const bool neg = inv[k] < 0.0f;
+        nq[k] = neg ? hi[k] : lo[k]; fq[k] = neg ? lo[k] : hi[k];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float t0 = tnear, t1 = tb;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float qa = (float)((nq[k] >> (8 * c)) & 0xffu), qb = (float)((fq[k] >> (8 * c)) & 0xffu);
+            t0 = fmaxf(t0, fmaf(qa, A[k], B[k])); t1 = fminf(t1, fmaf(qb, A[k], B[k]));     // NaN (d = 0) is dropped by fmin/fmax
+        }
+        const int ch = c == 0 ? c0 : (c == 1 ? c1 : (c == 2 ? c2 : c3));
+        const bool h = (ch != GDPT_CHILD_EMPTY) && (t0 <= t1);
         w.key[c] = h ? ((__float_as_uint(t0) & ~3u) | (unsigned)c) : kMissKey;
     }
 #define GDPT_CSWAP(i, j) { unsigned lo_ = min(w.key[i], w.key[j]), hi_ = max(w.key[i], w.key[j]); w.key[i] = lo_; w.key[j] = hi_; }
@@ -375,7 +416,8 @@ GD void trav_node(const TraceCtx &tx, const float oi[3], const float inv[3], flo
                          : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6) : "v"(np) : "memory");
         }
 #endif
-        visit_wide<!HBM>(tx.nodes4[cur], oi, inv, tnear, tb, w);
+        if (HBM && GDPT_HBM_Q4) visit_wide_q4(tx.nodes4q[cur], oi, inv, tnear, tb, w);
+        else visit_wide<!HBM>(tx.nodes4[cur], oi, inv, tnear, tb, w);
         if (w.key[0] != kMissKey) {
             if (w.key[3] != kMissKey) trav_push(tx, sp, w.ch[3]);
             if (w.key[2] != kMissKey) trav_push(tx, sp, w.ch[2]);
@@ -864,12 +906,12 @@ GD TraceCtx setup_trace(const DevSceneView &sv, unsigned char *s_scene, int *s_s
         for (int i = tid; i < lw; i += nthreads) dst[l0 + i] = s4[i];
         __syncthreads();
         tx.lights = (const double *)(s_scene + (size_t)l0 * 4);
-        tx.nodes = (const DevBvhNode *)s_scene; tx.nodes4 = (const DevBvh4Node *)s_scene; tx.nodes8 = nullptr;
+        tx.nodes = (const DevBvhNode *)s_scene; tx.nodes4 = (const DevBvh4Node *)s_scene; tx.nodes8 = nullptr; tx.nodes4q = nullptr;
         tx.prims = (const DevPrim *)(s_scene + (size_t)nw * 4);
         tx.tris = (const DevTriShade *)(s_scene + (size_t)(nw + pw) * 4);
         tx.materials = (const GdptMaterial *)(s_scene + (size_t)(nw + pw + tw) * 4);
     } else {
-        tx.nodes = sv.nodes; tx.nodes4 = sv.nodes4; tx.nodes8 = sv.nodes8; tx.prims = sv.prims; tx.tris = sv.tris; tx.materials = sv.materials;
+        tx.nodes = sv.nodes; tx.nodes4 = sv.nodes4; tx.nodes8 = sv.nodes8; tx.nodes4q = sv.nodes4q; tx.prims = sv.prims; tx.tris = sv.tris; tx.materials = sv.materials;
         tx.lights = sv.light_intensity;
     }
     return tx;

@@ -19,6 +19,7 @@ struct RenderLaunch {
     int spp;
     int rng_scheme;                // GDPT_RNG_*
     int row_begin, row_end;
+    int plan_rows;                 // the work-item plan is made for a band of this many rows (GdptRenderParams::plan_rows, resolved)
     int max_depth;                 // effective (scene value or override)
     double *img, *cx0, *cy0, *cx1, *cy1;   // device, W*H*3 each
     RenderCounters *counters;      // device
@@ -67,7 +68,7 @@ void launch_path_render(const DevSceneView &sv, const RenderLaunch &rl, hipStrea
 // Chunk sizes shrink along the queue (about 40 % of what is left each time, ending in single samples) unless
 // force_log2k >= 0 asks for 2^k equal chunks (tests). `lanes` = resident lanes of the persistent grid.
 ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long lanes);
-size_t render_partials_doubles(int width, int rows, int film_height, int spp, int force_log2k, long long lanes);
+size_t render_partials_doubles(int width, int rows, int plan_rows, int spp, int force_log2k, long long lanes);
 
 int wf_words();
 int wf_max_generations();

@@ -13,10 +13,13 @@ const char *render_kernel_name(int rng_scheme) {
 static long long resident_lanes(const RenderLaunch &rl) { return (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * gd::kBlock; }
 
 // item layout of the persistent kernels (render_device.h: item_to_pixel)
-// The plan is made for the WHOLE film, whatever band is rendered: a pixel's samples are cut (and its partial sums
-// merged) the same way on one device and on eight, so sharded renders equal the unsharded one bit for bit.
-static void set_chunks(gd::KernelArgs &a, const RenderLaunch &rl, int W, int rows, int film_h) {
-    const ChunkPlan plan = make_chunk_plan(rl.spp, rl.force_log2k, (long long)W * film_h, resident_lanes(rl));
+// The plan is made for a band of rl.plan_rows rows (default: the whole film), whatever band is rendered: a pixel's samples
+// are cut (and its partial sums merged) the same way by every render that names the same plan_rows, so a sharded render
+// equals the unsharded one with that plan bit for bit. (Round 2 always planned for the whole film: a 64-row band of the
+// 512x512x256 film, 1/8 of the work, then held 32 k items of 128 samples and took 9.3 ms instead of 3.8 —
+// profiles/r03_band_costs.txt.)
+static void set_chunks(gd::KernelArgs &a, const RenderLaunch &rl, int W, int rows) {
+    const ChunkPlan plan = make_chunk_plan(rl.spp, rl.force_log2k, (long long)W * rl.plan_rows, resident_lanes(rl));
     a.num_chunks = plan.n;
     for (int c = 0; c <= plan.n; c++) a.chunk_begin[c] = plan.begin[c];
     a.tiles_x = (W + 15) / 16;
@@ -67,7 +70,7 @@ static void run_wavefront(const DevSceneView &sv, const gd::KernelArgs &a, const
         w.cell_scale[k] = (hi > lo) ? 16.0f / (hi - lo) : 0.0f;
     }
     gd::WfTrace t{};
-    t.nodes4 = sv.nodes4; t.prims = sv.prims; t.spheres = sv.spheres; t.rays = w.rays; t.hits = w.hits; t.live = w.live;
+    t.nodes4 = sv.nodes4; t.nodes4q = sv.nodes4q; t.prims = sv.prims; t.spheres = sv.spheres; t.rays = w.rays; t.hits = w.hits; t.live = w.live;
     t.ovf = (int *)(aux + lay.ovf); t.ovf_stride = (unsigned)rl.wf_slots; t.counters = rl.counters;
     t.num_tris = sv.num_tris; t.num_nodes4 = sv.num_nodes4; t.num_spheres = sv.num_spheres; t.search_frac = a.thresh_c; t.count_stats = a.count;
     auto ckh = [](hipError_t e, const char *what) { if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e)); };
@@ -151,7 +154,7 @@ void launch_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t s
             launch_eager(sv, a, dim3((unsigned)(a.tiles_x * tiles_y)), stream);
         } else {
             // persistent lanes pulling (pixel, chunk) items: >= 4 samples per item, at most 8 items per pixel
-            set_chunks(a, rl, W, rows, sv.cam.height);
+            set_chunks(a, rl, W, rows);
             if (a.num_items >= (1LL << 32)) throw std::runtime_error("launch_render: image band too large for the 32-bit work queue");
             // scenes walked from HBM: stack slots = the tree's own bound (host-verified at upload)
             a.stack_levels = rl.wide_stack_need > 0 ? rl.wide_stack_need : GDPT_BVH_MAX_DEPTH;
@@ -197,7 +200,7 @@ void launch_path_render(const DevSceneView &sv, const RenderLaunch &rl, hipStrea
         // persistent lanes pulling (pixel, chunk) items, as the GradPath kernel does
         a.thresh_a = rl.thresh_a >= 0 ? (rl.thresh_a > 255 ? 255 : rl.thresh_a) : 64;
         a.thresh_c = rl.thresh_c >= 0 ? (rl.thresh_c > 255 ? 255 : rl.thresh_c) : 112;
-        set_chunks(a, rl, W, rows, sv.cam.height);
+        set_chunks(a, rl, W, rows);
         if (a.num_items >= (1LL << 32)) throw std::runtime_error("launch_path_render: image band too large for the 32-bit work queue");
         a.partials = rl.partials; a.queue_head = rl.queue_head;
         if (!a.partials || !a.queue_head) throw std::runtime_error("launch_path_render: work-queue buffers missing");
@@ -274,9 +277,9 @@ ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long 
     return p;
 }
 
-size_t render_partials_doubles(int width, int rows, int film_height, int spp, int force_log2k, long long lanes) {
+size_t render_partials_doubles(int width, int rows, int plan_rows, int spp, int force_log2k, long long lanes) {
     const long long tiles = (long long)((width + 15) / 16) * ((rows + 15) / 16);
-    return (size_t)16 * (size_t)(tiles * 256) * (size_t)make_chunk_plan(spp, force_log2k, (long long)width * film_height, lanes).n;
+    return (size_t)16 * (size_t)(tiles * 256) * (size_t)make_chunk_plan(spp, force_log2k, (long long)width * plan_rows, lanes).n;
 }
 
 bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_materials, int num_lights, int bvh_depth) {

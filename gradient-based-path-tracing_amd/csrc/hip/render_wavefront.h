@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void gdpt_wf_step(DevSceneView sv, KernelAr
     TraceCtx tx;
     tx.count = false; tx.need_uv = !sv.all_textures_constant;
     tx.stack = nullptr; tx.stride = 0;
-    tx.nodes = sv.nodes; tx.nodes4 = sv.nodes4; tx.nodes8 = sv.nodes8; tx.prims = sv.prims; tx.tris = sv.tris; tx.materials = sv.materials; tx.lights = sv.light_intensity;
+    tx.nodes = sv.nodes; tx.nodes4 = sv.nodes4; tx.nodes8 = sv.nodes8; tx.nodes4q = sv.nodes4q; tx.prims = sv.prims; tx.tris = sv.tris; tx.materials = sv.materials; tx.lights = sv.light_intensity;
     AccMem acc; acc.slot = (double *)(S + (long long)WF_ACC * N); acc.stride = N;
     LanePriv lp; lp.slot = (double *)(S + (long long)WF_PRIV * N); lp.stride = (int)N;
 
@@ -291,6 +291,7 @@ constexpr int kWfLdsLevels = 16;          // stack levels per lane in LDS (8 wav
 
 struct WfTrace {
     const DevBvh4Node *nodes4;
+    const DevBvh4QNode *nodes4q;    // GDPT_HBM_Q4 builds: the walk reads these instead
     const DevPrim *prims;
     const DevSphere *spheres;
     const float4 *rays;
@@ -427,7 +428,8 @@ __global__ __launch_bounds__(kWfTraceBlock, COUNT ? 4 : kWfTraceWaves) void gdpt
                     if (COUNT) { n_nodes++; if (wave_leader()) n_node_trips++; }
                     WideVisit wv;
                     // tfar of the boxes = the best hit so far (a sphere's, before the first triangle)
-                    visit_wide<false>(t.nodes4[cur], oi, inv, tnear, best.t, wv);
+                    if (GDPT_HBM_Q4) visit_wide_q4(t.nodes4q[cur], oi, inv, tnear, best.t, wv);
+                    else visit_wide<false>(t.nodes4[cur], oi, inv, tnear, best.t, wv);
                     if (wv.key[0] != kMissKey) {
                         if ((spa >> 10) + 3u <= (unsigned)kWfLdsLevels) {           // (the usual case: all three slots in LDS)
                             if (wv.key[3] != kMissKey) { lds(spa) = wv.ch[3]; spa += 1024u; }

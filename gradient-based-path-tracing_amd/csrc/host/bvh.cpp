@@ -340,6 +340,43 @@ std::vector<DevBvh8Node> collapse_bvh8(const std::vector<DevBvhNode> &nodes, int
     return out;
 }
 
+std::vector<DevBvh4QNode> quantise_bvh4(const std::vector<DevBvh4Node> &nodes) {
+    static_assert(sizeof(DevBvh4QNode) == 64, "quantised BVH4 node is half a 128-byte line");
+    std::vector<DevBvh4QNode> out(nodes.size());
+    for (size_t i = 0; i < nodes.size(); i++) {
+        const DevBvh4Node &w = nodes[i];
+        DevBvh4QNode &nd = out[i];
+        std::memset(&nd, 0, sizeof(nd));
+        for (int c = 0; c < 4; c++) nd.child[c] = w.child[c];
+        for (int k = 0; k < 3; k++) {
+            float lo = std::numeric_limits<float>::infinity(), hi = -std::numeric_limits<float>::infinity();
+            for (int c = 0; c < 4; c++) if (w.child[c] != GDPT_CHILD_EMPTY && w.lo[k][c] <= w.hi[k][c]) { lo = std::min(lo, w.lo[k][c]); hi = std::max(hi, w.hi[k][c]); }
+            if (!(lo <= hi)) { lo = 0.f; hi = 0.f; }
+            const double ext = (double)hi - (double)lo;
+            float step = (float)(ext / 255.0);        // grid step: extent / 255 rounded up to fp32 (floor 2^-60: keeps step / d a normal number)
+            while ((double)step * 255.0 < ext) step = std::nextafterf(step, std::numeric_limits<float>::infinity());
+            step = std::max(step, 0x1p-60f);
+            for (int tries = 0;; tries++) {
+                const double sc = (double)step;
+                bool ok = true;
+                for (int c = 0; c < 4 && ok; c++) {
+                    if (w.child[c] == GDPT_CHILD_EMPTY || !(w.lo[k][c] <= w.hi[k][c])) { nd.qlo[k][c] = 255; nd.qhi[k][c] = 0; continue; }   // (never read as a box: the child id decides)
+                    double ql = std::floor(((double)w.lo[k][c] - (double)lo) / sc), qh = std::ceil(((double)w.hi[k][c] - (double)lo) / sc);
+                    while (ql > 0 && (double)lo + ql * sc > (double)w.lo[k][c]) ql -= 1;
+                    while ((double)lo + qh * sc < (double)w.hi[k][c]) qh += 1;
+                    if (ql < 0) ql = 0;
+                    if (qh > 255) { ok = false; break; }
+                    nd.qlo[k][c] = (uint8_t)ql; nd.qhi[k][c] = (uint8_t)qh;
+                }
+                if (ok) { nd.org[k] = lo; nd.scale[k] = step; break; }
+                if (tries > 64 || !std::isfinite(step)) throw std::runtime_error("quantise_bvh4: box extent out of range");
+                step *= 1.0001f;
+            }
+        }
+    }
+    return out;
+}
+
 WideBvh collapse_for_traversal(const std::vector<DevBvhNode> &nodes, bool with_bvh8) {
     WideBvh w;
     w.nodes = collapse_bvh4(nodes, 4, GDPT_BVH_MAX_DEPTH, &w.stack_need);

@@ -29,6 +29,10 @@ std::vector<DevBvh4Node> collapse_bvh4(const std::vector<DevBvhNode> &nodes, int
 // always enclosing the boxes they replace). Same stack rule.
 std::vector<DevBvh8Node> collapse_bvh8(const std::vector<DevBvhNode> &nodes, int stack_slots, int *stack_need);
 
+// DevBvh4QNode form of a BVH4 (same topology and indices; child boxes on a per-node 8-bit grid that encloses them, checked in
+// double). Throws if a box cannot be represented.
+std::vector<DevBvh4QNode> quantise_bvh4(const std::vector<DevBvh4Node> &nodes);
+
 // The wide trees the device walks (stack bounds <= GDPT_BVH_MAX_DEPTH slots); arity = widest BVH4 node present.
 struct WideBvh { std::vector<DevBvh4Node> nodes; std::vector<DevBvh8Node> nodes8; int arity = 0, stack_need = 0, stack_need8 = 0; };
 // with_bvh8: also the quantised 8-wide form (the host check and the GDPT_HBM_BVH8 A/B build; product uploads do not need it)

@@ -1,6 +1,7 @@
 // image_io.cpp — see image_io.h. Own writers (the reference vendors tinyexr/stb_image).
 #include "image_io.h"
 #include "jpeg_decode.h"
+#include "png_decode.h"
 
 #include <zlib.h>
 
@@ -503,7 +504,8 @@ void load_texture_file(const std::string &path, int channels, int *width, int *h
             }
             return;
         }
-        if (ends_with(low, ".jpg") || ends_with(low, ".jpeg")) {
+        const bool is_png = ends_with(low, ".png");
+        if (ends_with(low, ".jpg") || ends_with(low, ".jpeg") || is_png) {
             // decoded natively; 8-bit -> linear exactly as stbi_loadf widens it: (float)(pow(v / 255.0f, 2.2f) * 1.0f),
             // the float overload of pow as image.cpp (C++) resolves it (src/3rdparty/stb_image.h:1849)
             std::ifstream jf(path, std::ios::binary);
@@ -511,7 +513,8 @@ void load_texture_file(const std::string &path, int channels, int *width, int *h
             std::vector<unsigned char> bytes((std::istreambuf_iterator<char>(jf)), std::istreambuf_iterator<char>());
             std::vector<uint8_t> px;
             try {
-                decode_jpeg(bytes.data(), bytes.size(), channels, width, height, &px);
+                if (is_png) decode_png(bytes.data(), bytes.size(), channels, width, height, &px);
+                else decode_jpeg(bytes.data(), bytes.size(), channels, width, height, &px);
             } catch (const std::exception &e) {
                 throw std::runtime_error("Failure when loading image: " + path + " (" + e.what() + ")");
             }

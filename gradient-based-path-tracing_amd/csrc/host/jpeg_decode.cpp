@@ -1,4 +1,4 @@
-// jpeg_decode.cpp — baseline (sequential Huffman, 8-bit) JPEG decoder for <texture type="bitmap"> inputs.
+// jpeg_decode.cpp — baseline and progressive (Huffman, 8-bit) JPEG decoder for <texture type="bitmap"> inputs.
 //
 // The reference reads bitmaps through stb_image v2.27 (stbi_loadf in imread1/imread3, src/image.cpp:26-108; the
 // library is vendored at src/3rdparty/stb_image.h). Texels are data on the hot path (Q6 of SURVEY §8), so this decoder
@@ -11,6 +11,9 @@
 //     (3*t0+t1+8)>>4 for 2x2                                                            (:3411-3474)
 //   * YCbCr -> RGB in 20-bit fixed point with the constants rounded to 12 bits first     (:3604-3630)
 //   * a 1-channel request of a YCbCr file returns the Y plane itself                      (:3826-3829)
+//   * progressive files (SOF2; T.81 Annex G: spectral selection + successive approximation) accumulate their
+//     coefficients over the scans as int16, first DC scan zeroing the block; they are dequantised (product truncated to
+//     int16, with the tables in effect at the end of the file) and transformed once, after the last scan   (:2113-2290, :3092-3113)
 // stb's SIMD kernels are written to be bit-identical to these scalar forms (its own comments at :2492, :3604).
 // Pinned by tests/golden/ref_textures.json, made with the reference's own image.cpp (oracle/ref_img.cpp).
 #include "jpeg_decode.h"
@@ -54,6 +57,8 @@ struct Component {
     int x = 0, y = 0, w2 = 0, h2 = 0;    // sample extent, padded plane extent
     int dc_pred = 0;
     std::vector<uint8_t> plane;
+    std::vector<int16_t> coeff;          // progressive files: 64 coefficients per block of the padded plane, block-row-major
+    int coeff_w = 0;                     // blocks per row of `coeff`
 };
 
 struct BitReader {
@@ -183,6 +188,8 @@ struct Decoder {
     int adobe_transform = -1;
     int rgb_ids = 0;
     bool have_frame = false, scanned = false;
+    bool progressive = false;
+    int spec_start = 0, spec_end = 63, succ_high = 0, succ_low = 0, eob_run = 0;     // progressive scan parameters
     uint16_t quant[4][64];
     HuffTable dc_tab[4], ac_tab[4];
     Component comp[4];
@@ -243,7 +250,7 @@ struct Decoder {
         pos += (size_t)L;
     }
     void read_sof(int m) {
-        if (m == 0xC2) throw std::runtime_error("progressive JPEG is not supported (baseline only)");
+        progressive = (m == 0xC2);
         int Lf = u16();
         if (u8() != 8) throw std::runtime_error("JPEG: only 8-bit samples");
         height = u16(); width = u16();
@@ -270,6 +277,7 @@ struct Decoder {
             c.y = (height * c.v + v_max - 1) / v_max;
             c.w2 = mcu_x * c.h * 8; c.h2 = mcu_y * c.v * 8;
             c.plane.assign((size_t)c.w2 * c.h2, 0);
+            if (progressive) { c.coeff_w = c.w2 / 8; c.coeff.assign((size_t)c.w2 * c.h2, 0); }
         }
         have_frame = true;
     }
@@ -298,6 +306,91 @@ struct Decoder {
         }
     }
 
+    // ---- progressive scans (T.81 G.1.2): coefficients accumulate in Component::coeff, un-dequantised ----
+    void prog_dc(BitReader &br, Component &c, int16_t *blk) {
+        if (spec_end != 0) throw std::runtime_error("progressive JPEG: DC and AC in one scan");
+        if (succ_high == 0) {                           // first DC scan: the block starts here
+            std::memset(blk, 0, 64 * sizeof(int16_t));
+            const HuffTable &hd = dc_tab[c.td];
+            if (!hd.defined) throw std::runtime_error("missing Huffman table");
+            int t = br.decode(hd);
+            if (t > 15) throw std::runtime_error("bad DC size");
+            int dc = c.dc_pred + br.receive_extend(t);
+            c.dc_pred = dc;
+            blk[0] = (int16_t)(dc * (1 << succ_low));
+        } else if (br.get_bit()) blk[0] = (int16_t)(blk[0] + (int16_t)(1 << succ_low));      // refinement: one more bit
+    }
+    void prog_ac(BitReader &br, Component &c, int16_t *blk) {
+        if (spec_start == 0) throw std::runtime_error("progressive JPEG: DC and AC in one scan");
+        const HuffTable &ha = ac_tab[c.ta];
+        if (!ha.defined) throw std::runtime_error("missing Huffman table");
+        if (succ_high == 0) {                           // first pass over this band
+            if (eob_run) { --eob_run; return; }
+            int k = spec_start;
+            do {
+                int rs = br.decode(ha), s = rs & 15, r = rs >> 4;
+                if (s == 0) {
+                    if (r < 15) {                       // end of band for 2^r (+ extra bits) blocks, this one included
+                        eob_run = 1 << r;
+                        if (r) eob_run += br.get_bits(r);
+                        --eob_run;
+                        break;
+                    }
+                    k += 16;
+                } else {
+                    k += r;
+                    if (k > 63) throw std::runtime_error("bad AC run");
+                    int z = kZigzag[k++];
+                    blk[z] = (int16_t)(br.receive_extend(s) * (1 << succ_low));
+                }
+            } while (k <= spec_end);
+        } else {                                        // refinement pass: one more bit for known coefficients, new +-1s
+            const int16_t bit = (int16_t)(1 << succ_low);
+            auto refine = [&](int16_t *p) { if (br.get_bit() && (*p & bit) == 0) *p = (int16_t)(*p > 0 ? *p + bit : *p - bit); };
+            if (eob_run) {
+                --eob_run;
+                for (int k = spec_start; k <= spec_end; k++) { int16_t *p = &blk[kZigzag[k]]; if (*p != 0) refine(p); }
+            } else {
+                int k = spec_start;
+                do {
+                    int rs = br.decode(ha), s = rs & 15, r = rs >> 4;
+                    if (s == 0) {
+                        if (r < 15) {
+                            eob_run = (1 << r) - 1;
+                            if (r) eob_run += br.get_bits(r);
+                            r = 64;                     // run to the end of the band, refining what is there
+                        }                               // r == 15: sixteen zeros = a run of 15 and a zero "new" value
+                    } else {
+                        if (s != 1) throw std::runtime_error("bad AC refinement");
+                        s = br.get_bit() ? bit : -bit;
+                    }
+                    while (k <= spec_end) {
+                        int16_t *p = &blk[kZigzag[k++]];
+                        if (*p != 0) refine(p);
+                        else {
+                            if (r == 0) { *p = (int16_t)s; break; }
+                            --r;
+                        }
+                    }
+                } while (k <= spec_end);
+            }
+        }
+    }
+    // after the last scan: dequantise (truncated to int16, like the sequential path) and transform every block
+    void finish_progressive() {
+        for (int n = 0; n < ncomp; n++) {
+            Component &c = comp[n];
+            const uint16_t *dq = quant[c.tq];
+            const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+            for (int j = 0; j < bh; j++)
+                for (int i = 0; i < bw; i++) {
+                    int16_t *blk = c.coeff.data() + 64 * ((size_t)i + (size_t)j * c.coeff_w);
+                    for (int k = 0; k < 64; k++) blk[k] = (int16_t)(blk[k] * dq[k]);
+                    idct_block(c.plane.data() + (size_t)c.w2 * j * 8 + i * 8, c.w2, blk);
+                }
+        }
+    }
+
     void read_scan() {
         if (!have_frame) throw std::runtime_error("SOS before SOF");
         int Ls = u16(), n = u8();
@@ -311,10 +404,17 @@ struct Decoder {
             if (comp[which].td > 3 || comp[which].ta > 3) throw std::runtime_error("bad SOS table");
             order[i] = which;
         }
-        int ss = u8(); u8(); int ahl = u8();
-        if (ss != 0 || ahl != 0) throw std::runtime_error("bad SOS (not sequential)");
+        spec_start = u8(); spec_end = u8();
+        { int ahl = u8(); succ_high = ahl >> 4; succ_low = ahl & 15; }
+        if (progressive) {
+            if (spec_start > 63 || spec_end > 63 || spec_start > spec_end || succ_high > 13 || succ_low > 13) throw std::runtime_error("bad SOS (progressive)");
+        } else {
+            if (spec_start != 0 || succ_high != 0 || succ_low != 0) throw std::runtime_error("bad SOS (not sequential)");
+            spec_end = 63;
+        }
         BitReader br{data + pos, data + size};
         for (int k = 0; k < ncomp; k++) comp[k].dc_pred = 0;
+        eob_run = 0;
         int todo = restart_interval ? restart_interval : 0x7fffffff;
         int16_t blk[64];
         auto restart_check = [&]() {
@@ -323,17 +423,22 @@ struct Decoder {
             if (!(br.marker >= 0xD0 && br.marker <= 0xD7)) return false;     // no restart marker: the scan is over
             br.reset();
             for (int k = 0; k < ncomp; k++) comp[k].dc_pred = 0;
+            eob_run = 0;
             todo = restart_interval ? restart_interval : 0x7fffffff;
             return true;
         };
+        auto block_at = [&](Component &c, int bx, int by) { return c.coeff.data() + 64 * ((size_t)bx + (size_t)by * c.coeff_w); };
         if (n == 1) {                                   // non-interleaved: the component's own block grid
             Component &c = comp[order[0]];
             int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
             bool go = true;
             for (int j = 0; j < bh && go; j++)
                 for (int i = 0; i < bw && go; i++) {
-                    decode_block(br, c, blk);
-                    idct_block(c.plane.data() + (size_t)c.w2 * j * 8 + i * 8, c.w2, blk);
+                    if (progressive) { if (spec_start == 0) prog_dc(br, c, block_at(c, i, j)); else prog_ac(br, c, block_at(c, i, j)); }
+                    else {
+                        decode_block(br, c, blk);
+                        idct_block(c.plane.data() + (size_t)c.w2 * j * 8 + i * 8, c.w2, blk);
+                    }
                     go = restart_check();
                 }
         } else {                                        // interleaved MCUs
@@ -345,6 +450,7 @@ struct Decoder {
                         for (int y = 0; y < c.v; y++)
                             for (int x = 0; x < c.h; x++) {
                                 int x2 = (i * c.h + x) * 8, y2 = (j * c.v + y) * 8;
+                                if (progressive) { prog_dc(br, c, block_at(c, x2 / 8, y2 / 8)); continue; }     // (interleaved scans carry DC only)
                                 decode_block(br, c, blk);
                                 idct_block(c.plane.data() + (size_t)c.w2 * y2 + x2, c.w2, blk);
                             }
@@ -384,6 +490,7 @@ struct Decoder {
             }
         }
         if (!scanned) throw std::runtime_error("JPEG without image data");
+        if (progressive) finish_progressive();
     }
 };
 

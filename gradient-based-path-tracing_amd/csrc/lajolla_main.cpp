@@ -13,6 +13,8 @@
 //   --gpus N      shard the tile loop into N row bands over devices 0..N-1 (gdpt_multi_*: one host thread per GPU, as
 //                 the reference's -t threads share the tile grid, src/parallel.cpp:183-256); --devices a,b,.. names them
 //   --exchange rccl|peer   transport of the halo row + all-gather between the bands (default rccl)
+//   --plan-rows R   cut every pixel's samples into work items as for a band of R rows (GdptRenderParams::plan_rows): a
+//                 single-device run with the R of an N-band run (its largest band) writes that run's image bit for bit
 // `-t` is accepted for compatibility; rendering runs on the GPU, so it has no effect.
 #include "../../include/gdpt.h"
 
@@ -29,7 +31,7 @@ int main(int argc, char *argv[]) {
         return 0;
     }
     int num_threads = 0, spp = 0, device = 0, rng = GDPT_RNG_SAMPLE, shift = GDPT_SHIFT_REFERENCE;
-    int film_w = 0, film_h = 0;
+    int film_w = 0, film_h = 0, plan_rows = 0;
     GdptMultiConfig multi{};          // num_devices == 0: single-device entry points
     double alpha = 0.04;
     std::string outputfile = "";
@@ -72,6 +74,7 @@ int main(int argc, char *argv[]) {
             else if (v == "peer") multi.exchange = GDPT_EXCHANGE_PEER_COPY;
             else { std::cerr << "unknown --exchange " << v << " (rccl | peer)" << std::endl; return 2; }
         }
+        else if (a == "--plan-rows") plan_rows = std::stoi(next());
         else if (a == "--rng") { std::string v = next(); rng = (v == "tile") ? GDPT_RNG_TILE : GDPT_RNG_SAMPLE; }
         else if (a == "--shift") {        // extension: "reconnect" = GDPT_SHIFT_RECONNECT (include/gdpt.h); default = the reference's offsets
             std::string v = next();
@@ -109,7 +112,7 @@ int main(int argc, char *argv[]) {
         const int w = desc->camera.width, h = desc->camera.height;
         std::vector<double> image((size_t)w * h * 3);
         GdptRenderParams p{};
-        p.spp = spp; p.rng_scheme = rng; p.shift_mode = shift;
+        p.spp = spp; p.rng_scheme = rng; p.shift_mode = shift; p.plan_rows = plan_rows;
         GdptRenderStats rs{};
         GdptPoissonStats ps{};
         GdptMultiStats ms{};

@@ -41,49 +41,80 @@ def all_bands(height, world):
     return [band_rows(height, world, r) for r in range(world)]
 
 
-def gather_bands(dist, buf, height, world, rank):
+def bands_weighted(height, world, costs):
+    """Bands of whole tile rows whose largest COST is as small as a contiguous split allows; `costs[t]` >= 0 is the measured
+    cost of tile row t (Scene.tile_row_costs: rays of a pilot render). Linear partition by dynamic programming, ties to the
+    split found first — the mirror of gdpt_band_rows_weighted (csrc/hip/multi_gpu.hip), cut for cut. With fewer tile rows than
+    ranks the last ranks own nothing, as in band_rows."""
+    T = (height + TILE - 1) // TILE
+    if len(costs) != T:
+        raise ValueError("one cost per 16-pixel tile row expected")
+    if any(not (c >= 0.0) for c in costs):
+        raise ValueError("negative or non-finite cost")
+    used = min(world, T)
+    pre = [0.0]
+    for c in costs:
+        pre.append(pre[-1] + float(c))
+    inf = 1e300
+    best = [[inf] * (T + 1) for _ in range(used + 1)]
+    cut = [[0] * (T + 1) for _ in range(used + 1)]
+    best[0][0] = 0.0
+    for k in range(1, used + 1):
+        for t in range(k, T - (used - k) + 1):
+            for s in range(k - 1, t):
+                if best[k - 1][s] >= inf:
+                    continue
+                v = max(best[k - 1][s], pre[t] - pre[s])
+                if v < best[k][t]:
+                    best[k][t], cut[k][t] = v, s
+    first = [T] * (world + 1)
+    t = T
+    for k in range(used, 0, -1):
+        first[k] = t
+        t = cut[k][t]
+    first[0] = 0
+    return [(min(first[r] * TILE, height), min(first[r + 1] * TILE, height)) for r in range(world)]
+
+
+def gather_bands(dist, buf, height, world, rank, bands=None):
     """In-place all-gather of one HxWx3 image whose rows [r0,r1) are valid on this rank.
-    Bands are contiguous row ranges ordered by rank, so the gathered image is the concatenation."""
+    Bands are contiguous row ranges ordered by rank, so the gathered image is the concatenation. Equal bands: one in-place
+    all-gather. Ragged bands (tile rows that do not divide evenly, cost-balanced bands, ranks that own nothing): one
+    in-place broadcast per band, issued together — what the C host does with grouped ncclBroadcast."""
     if world == 1:
         return buf
-    bands = all_bands(height, world)
+    bands = all_bands(height, world) if bands is None else bands
     r0, r1 = bands[rank]
-    sizes = {b[1] - b[0] for b in bands}
     wire = wire_device(dist, buf)
     if wire != buf.device:            # gloo over device tensors: gather a host copy, write it back
         host = buf.to(wire)
-        gather_bands(dist, host, height, world, rank)
+        gather_bands(dist, host, height, world, rank, bands)
         buf.copy_(host)
         return buf
-    mine = buf[r0:r1].reshape(-1)
-    if len(sizes) == 1 and bands[-1][1] == height:
-        dist.all_gather_into_tensor(buf.view(-1), mine.clone())
-    else:  # ragged bands (tile rows do not divide evenly, or some ranks own nothing): pad to the largest band
-        row_elems = buf.shape[1] * buf.shape[2]
-        biggest = max(b[1] - b[0] for b in bands) * row_elems
-        send = buf.new_zeros((biggest,))
-        send[:mine.numel()] = mine
-        parts = [buf.new_empty((biggest,)) for _ in bands]
-        dist.all_gather(parts, send)
-        for b, p in zip(bands, parts):
-            if b[1] > b[0]:
-                buf[b[0]:b[1]] = p[:(b[1] - b[0]) * row_elems].view(b[1] - b[0], buf.shape[1], buf.shape[2])
+    if equal_bands(height, world, bands):
+        flat = buf.view(-1)
+        n = (r1 - r0) * buf.shape[1] * buf.shape[2]
+        dist.all_gather_into_tensor(flat, flat[rank * n:(rank + 1) * n])
+    else:
+        works = [dist.broadcast(buf[b[0]:b[1]], src=r, async_op=True) for r, b in enumerate(bands) if b[1] > b[0]]
+        for wk in works:
+            wk.wait()
     return buf
 
 
-def equal_bands(height, world):
-    """True when every rank owns the same, non-zero number of rows (the packed single-collective path applies)."""
-    bands = all_bands(height, world)
+def equal_bands(height, world, bands=None):
+    """True when every rank owns the same, non-zero number of rows (the in-place all-gather applies)."""
+    bands = all_bands(height, world) if bands is None else bands
     sizes = {b[1] - b[0] for b in bands}
     return len(sizes) == 1 and bands[-1][1] == height and bands[0][1] > bands[0][0]
 
 
-def halo_exchange_cy1(dist, cy1, height, world, rank):
+def halo_exchange_cy1(dist, cy1, height, world, rank, bands=None):
     """Row r0-1 of `cy1` (HxWx3) is filled with the last row of the band above (owned by rank-1); this rank's last
     row goes to rank+1. Point-to-point, W*3 values each way."""
     if world == 1:
         return cy1
-    bands = all_bands(height, world)
+    bands = all_bands(height, world) if bands is None else bands
     r0, r1 = bands[rank]
     ops, recv_row = [], None
     # neighbours by band adjacency (skip ranks that own nothing)
@@ -104,7 +135,7 @@ def halo_exchange_cy1(dist, cy1, height, world, rank):
     return cy1
 
 
-def gather_packed(dist, images, height, world, rank, scratch=None):
+def gather_packed(dist, images, height, world, rank, scratch=None, bands=None):
     """In-place all-gather of several HxWx3 images whose rows [r0,r1) are valid on this rank.
 
     Equal bands: bands are contiguous row ranges in rank order, so a rank's band already sits at its final offset
@@ -115,9 +146,9 @@ def gather_packed(dist, images, height, world, rank, scratch=None):
     is an optional dict reused across calls for those buffers."""
     if world == 1:
         return images
-    if not equal_bands(height, world):
+    if not equal_bands(height, world, bands):
         for im in images:
-            gather_bands(dist, im, height, world, rank)
+            gather_bands(dist, im, height, world, rank, bands)
         return images
     r0, r1 = band_rows(height, world, rank)
     n = len(images)
@@ -167,9 +198,13 @@ class ShardedGradPath:
 
     NAMES = ("img", "cx0", "cy0", "cx1", "cy1")
 
-    def __init__(self, dist, world, rank, height, new_image, render_band, assemble, solve, phase_hook=None):
+    def __init__(self, dist, world, rank, height, new_image, render_band, assemble, solve, phase_hook=None, bands=None):
         self.dist, self.world, self.rank, self.height = dist, int(world), int(rank), int(height)
-        self.rows = band_rows(self.height, self.world, self.rank)
+        # `bands`: every rank's rows (the same list on all ranks), e.g. bands_weighted(...); default: equal tile-row counts
+        self.bands = [tuple(b) for b in bands] if bands is not None else all_bands(self.height, self.world)
+        if len(self.bands) != self.world or self.bands[0][0] != 0 or any(a[1] != b[0] for a, b in zip(self.bands, self.bands[1:])) or self.bands[-1][1] != self.height:
+            raise ValueError("bands must be contiguous, rank-ordered and cover the film")
+        self.rows = self.bands[self.rank]
         self.render_band, self.assemble, self.solve = render_band, assemble, solve
         self.phase_hook = phase_hook or (lambda name: None)
         self.bufs = {k: new_image() for k in self.NAMES}
@@ -181,11 +216,11 @@ class ShardedGradPath:
         rstats = self.render_band(self.bufs, self.rows, want_stats) if r1 > r0 else None
         self.phase_hook("render")
         if self.world > 1:            # exchange 1: the last cy1 row of the band above (W*24 bytes, point to point)
-            halo_exchange_cy1(self.dist, self.bufs["cy1"], self.height, self.world, self.rank)
+            halo_exchange_cy1(self.dist, self.bufs["cy1"], self.height, self.world, self.rank, self.bands)
         if r1 > r0:
             self.assemble(self.bufs, (self.c, self.cx, self.cy), self.rows)
         if self.world > 1:            # exchange 2: the assembled bands, gathered in place
-            gather_packed(self.dist, [self.c, self.cx, self.cy], self.height, self.world, self.rank, self._scratch)
+            gather_packed(self.dist, [self.c, self.cx, self.cy], self.height, self.world, self.rank, self._scratch, self.bands)
         self.phase_hook("exchange")
         pstats = self.solve(self.c, self.cx, self.cy, self.out, want_stats)
         self.phase_hook("solve")

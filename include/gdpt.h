@@ -157,6 +157,13 @@ typedef struct GdptRenderParams {
                                   Rows outside the band are left untouched in the output buffers. */
     int32_t max_depth_override;/* 0 = use scene; else value */
     int32_t shift_mode;        /* GDPT_SHIFT_* (gdpt_render* only; 0 = the reference's behaviour) */
+    int32_t plan_rows;         /* 0 = film height. A pixel's samples are cut into work items ("chunks") whose partial sums are
+                                  merged in chunk order; the cut is made for a band of this many rows, so that a small band
+                                  rendered alone (one device of N) still consists of many short items instead of a few long
+                                  ones. Renders of the same pixel with the same plan_rows are bit-identical whatever band
+                                  they are part of: the multi-device hosts pass the rows of their largest band, and a
+                                  single-device render given the same value reproduces their images bit for bit. */
+    int32_t reserved;          /* 0 */
 } GdptRenderParams;
 
 typedef struct GdptRenderStats {
@@ -288,6 +295,10 @@ typedef struct GdptMultiConfig {
     int32_t num_devices;       /* 1..GDPT_MULTI_MAX_DEVICES */
     int32_t exchange;          /* GDPT_EXCHANGE_* */
     int32_t devices[GDPT_MULTI_MAX_DEVICES];   /* HIP device ordinals, band order */
+    int32_t balance;           /* 0: bands of equal tile-row count (gdpt_band_rows). 1: bands of equal measured cost — a pilot
+                                  render (1 spp, first device, at create time) counts the rays of every tile row and the
+                                  bands are cut by gdpt_band_rows_weighted */
+    int32_t reserved;          /* 0 */
 } GdptMultiConfig;
 typedef struct GdptMultiStats {
     int32_t num_devices, exchange;
@@ -303,6 +314,15 @@ typedef struct GdptMulti GdptMulti;   /* opaque: one uploaded scene, stream and 
 /* Rows [row_begin,row_end) of band `band` of `num_bands`: whole 16-pixel tile rows (src/render.cpp:271), balanced by
  * tile-row count, in band order. Host only. */
 int gdpt_band_rows(int height, int num_bands, int band, int32_t *row_begin, int32_t *row_end);
+/* The same with bands of (nearly) equal COST: tile_row_cost[t] >= 0 is the cost of tile row t (num_tile_rows =
+ * ceil(height / 16) of them); the split minimises the cost of the most expensive band among all contiguous splits into
+ * whole tile rows, rank-ordered. Host only. */
+int gdpt_band_rows_weighted(int height, int num_bands, int band, const double *tile_row_cost, int num_tile_rows,
+                            int32_t *row_begin, int32_t *row_end);
+/* Cost of every 16-pixel tile row of the film: rays traced by a pilot render of that tile row alone at `spp` samples per
+ * pixel (GDPT_RNG_SAMPLE, reference shift). Exact counts, so every caller — every rank of a sharded run — gets the same
+ * numbers. `capacity` >= ceil(height / 16). Blocking; what the multi-device hosts balance their bands by. */
+int gdpt_tile_row_costs(GdptScene *scene, int spp, double *cost, int capacity);
 int gdpt_multi_create(const GdptSceneDesc *desc, const GdptMultiConfig *config, GdptMulti **out);
 void gdpt_multi_free(GdptMulti *multi);
 /* Whole Integrator::GradPath on the device set; arguments as gdpt_gradient_path_render (params->row_begin/row_end

@@ -83,6 +83,10 @@ def gen_images():
     jpgs = sorted(glob.glob(os.path.join(ROOT, "scenes", "sponza", "textures", "*.JPG")))
     doc["imread3"] = json.loads(subprocess.check_output([exe, "hash3"] + jpgs))
     doc["imread1"] = json.loads(subprocess.check_output([exe, "hash1"] + jpgs))
+    # PNG (every colour type / depth / filter / Adam7) and progressive JPEG fixtures written by tests/golden/make_images.py
+    fx = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "images", "*.png")) + glob.glob(os.path.join(ROOT, "tests", "golden", "images", "*.jpg")))
+    doc["fixtures_imread3"] = json.loads(subprocess.check_output([exe, "hash3"] + fx))
+    doc["fixtures_imread1"] = json.loads(subprocess.check_output([exe, "hash1"] + fx))
     tmp = tempfile.mkdtemp()
     doc["exr"] = {}
     for (w, h) in ((19, 7), (8, 5), (40, 33)):

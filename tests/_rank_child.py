@@ -42,14 +42,18 @@ def main():
     def solve(c, cx, cy, out, want_stats):
         out.copy_(torch.from_numpy(O.fourier_solve(c.numpy(), cx.numpy(), cy.numpy(), 0.04)))
 
+    bands = None
+    if len(sys.argv) > 4 and sys.argv[4] == "weighted":          # cost-balanced bands from a pilot (the oracle's ray counts per tile row)
+        costs = [float(osc.render(1, G.RNG_SAMPLE, rows=(t * 16, min(H, t * 16 + 16)), threads=2)[1].rays) for t in range((H + 15) // 16)]
+        bands = sharding.bands_weighted(H, world, costs)
     pipe = sharding.ShardedGradPath(dist, world, rank, H, lambda: torch.zeros((H, W, 3), dtype=torch.float64),
-                                    render_band, assemble, solve)
+                                    render_band, assemble, solve, bands=bands)
     pipe.step()
     pipe.step()                                                  # a second step: scratch reuse, no stale state
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), out=pipe.out.numpy(), c=pipe.c.numpy(), cx=pipe.cx.numpy(), cy=pipe.cy.numpy())
     dist.barrier()
     if rank == 0:
-        print(json.dumps({"world": world, "rows": list(pipe.rows), "ok": True}))
+        print(json.dumps({"world": world, "rows": list(pipe.rows), "bands": [list(b) for b in pipe.bands], "ok": True}))
     dist.destroy_process_group()
 
 

@@ -16,17 +16,20 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
-@pytest.mark.parametrize("world,height", [(2, 64), (3, 80)])
-def test_launcher_runs_the_sharded_step_on_every_rank(G, O, scene_tmp, tmp_path, world, height, capfd):
+@pytest.mark.parametrize("world,height,bands", [(2, 64, "equal"), (3, 80, "equal"), (3, 112, "weighted")])
+def test_launcher_runs_the_sharded_step_on_every_rank(G, O, scene_tmp, tmp_path, world, height, bands, capfd):
     xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=24, height=height)
     sd = G.parse_scene(xml)
     whole, _ = O.OracleScene(sd.ptr).render(2, G.RNG_SAMPLE, threads=4)
     c, cx, cy = O.assemble(whole)
     want = O.fourier_solve(c, cx, cy, 0.04)
-    rc = bench.launch_ranks(world, [os.path.join(ROOT, "tests", "_rank_child.py"), xml, "2", str(tmp_path)], timeout=300)
+    rc = bench.launch_ranks(world, [os.path.join(ROOT, "tests", "_rank_child.py"), xml, "2", str(tmp_path), bands], timeout=300)
     assert rc == 0
-    line = [l for l in capfd.readouterr().out.splitlines() if l.startswith("{")][-1]      # rank 0's line came through the parent
-    assert json.loads(line)["world"] == world
+    line = json.loads([l for l in capfd.readouterr().out.splitlines() if l.startswith("{")][-1])      # rank 0's line came through the parent
+    assert line["world"] == world
+    if bands == "weighted":               # the cbox film is cheaper at the top (ceiling, light) than in the middle: the bands are not equal
+        from gdpt_amd import sharding
+        assert line["bands"] != [list(b) for b in sharding.all_bands(height, world)] and line["bands"][-1][1] == height
     for r in range(world):
         got = np.load(tmp_path / f"rank{r}.npz")
         for name, w in (("c", c), ("cx", cx), ("cy", cy), ("out", want)):

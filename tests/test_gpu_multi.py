@@ -33,13 +33,65 @@ def test_band_rows_of_the_c_host_equal_the_python_mirror(G):
                 assert a[1] == b[0] and (a[0] % 16 == 0 or a[0] == a[1] == height)      # bands without rows sit at the end
 
 
+def test_cost_balanced_bands_of_the_c_host_equal_the_python_mirror(G):
+    """gdpt_band_rows_weighted and sharding.bands_weighted cut the same bands: contiguous, whole tile rows, rank-ordered, and
+    no contiguous split has a cheaper most-expensive band (checked by brute force on small cases)."""
+    import itertools
+    from gdpt_amd import sharding
+    rng = np.random.default_rng(7)
+    for height in (16, 40, 64, 80, 200, 512, 720, 1024):
+        T = (height + 15) // 16
+        for costs in (np.ones(T), rng.uniform(0.5, 2.0, T), np.concatenate([np.full(T // 2, 1.0), np.full(T - T // 2, 3.0)]), np.zeros(T)):
+            for n in (1, 2, 3, 4, 8, 16):
+                bands = [G.band_rows_weighted(height, n, b, list(costs)) for b in range(n)]
+                assert bands == sharding.bands_weighted(height, n, list(costs)), (height, n)
+                assert bands[0][0] == 0 and bands[-1][1] == height
+                for a, b in zip(bands, bands[1:]):
+                    assert a[1] == b[0] and (a[0] % 16 == 0 or a[0] == a[1] == height)
+                owned = [b for b in bands if b[1] > b[0]]
+                assert len(owned) == min(n, T)
+                worst = max(costs[b[0] // 16:(b[1] + 15) // 16].sum() for b in owned)
+                if T <= 8:                                   # every split into min(n, T) non-empty runs
+                    k = min(n, T)
+                    for cuts in itertools.combinations(range(1, T), k - 1):
+                        edges = (0,) + cuts + (T,)
+                        assert max(costs[a:b].sum() for a, b in zip(edges, edges[1:])) >= worst - 1e-12
+    # uniform costs and a tile-row count the bands divide: the equal split
+    assert sharding.bands_weighted(512, 8, [1.0] * 32) == sharding.all_bands(512, 8)
+
+
+@pytest.mark.gpu
+def test_cost_balanced_device_set(G, scene_tmp):
+    """GdptMultiConfig.balance: the bands come from a pilot render's ray counts (gdpt_tile_row_costs) and
+    gdpt_band_rows_weighted; the image still equals the single-device image with the same work-item plan, and the same pilot
+    through the Python mirror cuts the same bands (what bench.py's ranks do)."""
+    from gdpt_amd import sharding
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=64, height=128)
+    sd = G.parse_scene(xml)
+    one = G.Scene(sd)
+    costs = one.tile_row_costs()
+    assert len(costs) == 8 and all(c > 0 for c in costs) and costs == one.tile_row_costs()      # exact counts: reproducible
+    bands = sharding.bands_weighted(128, 3, costs)
+    ms = G.MultiScene(sd, (0, 0, 0), exchange=G.EXCHANGE_PEER_COPY, balance=True)
+    out, bufs, rs, st = ms.gradient_path_render(5, G.RNG_SAMPLE, return_buffers=True)
+    assert [(st.row_begin[i], st.row_end[i]) for i in range(3)] == bands
+    want_out, want, wrs, _ = one.gradient_path_render(5, G.RNG_SAMPLE, return_buffers=True, plan_rows=max(b[1] - b[0] for b in bands))
+    assert np.array_equal(out, want_out)
+    for k in BUFS:
+        assert np.array_equal(bufs[k], want[k]), k
+    assert rs.rays == wrs.rays
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("devices,exchange,height", [((0,), "rccl", 64), ((0,), "peer", 64), ((0, 0), "peer", 64),
                                                      ((0, 0, 0), "peer", 80), ((0, 0, 0, 0), "peer", 48)])
 def test_multi_device_set_equals_single_device(G, scene_tmp, devices, exchange, height):
     xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=72, height=height)
     sd = G.parse_scene(xml)
-    want_out, want, wrs, _ = G.Scene(sd).gradient_path_render(6, G.RNG_SAMPLE, return_buffers=True)
+    # the device set cuts every pixel's samples for its largest band (GdptRenderParams.plan_rows); a single device given the
+    # same plan must produce the same bits
+    plan = max(b[1] - b[0] for b in (G.band_rows(height, len(devices), i) for i in range(len(devices))))
+    want_out, want, wrs, _ = G.Scene(sd).gradient_path_render(6, G.RNG_SAMPLE, return_buffers=True, plan_rows=plan)
     ms = G.MultiScene(sd, devices, exchange=G.EXCHANGE_RCCL if exchange == "rccl" else G.EXCHANGE_PEER_COPY)
     for _ in range(2):                                    # twice: no stale state between calls
         out, bufs, rs, st = ms.gradient_path_render(6, G.RNG_SAMPLE, return_buffers=True)
@@ -63,7 +115,7 @@ def test_a_band_that_fails_does_not_hang_the_others(G, scene_tmp, band, stage):
     The failure is injected by the test knobs multi_fail_band / multi_fail_stage (csrc/hip/multi_gpu.hip: rank_body)."""
     xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=48, height=80)
     sd = G.parse_scene(xml)
-    want_out, _, _, _ = G.Scene(sd).gradient_path_render(3, G.RNG_SAMPLE, return_buffers=True)
+    want_out, _, _, _ = G.Scene(sd).gradient_path_render(3, G.RNG_SAMPLE, return_buffers=True, plan_rows=32)   # bands of 32, 32, 16 rows
     ms = G.MultiScene(sd, (0, 0, 0), exchange=G.EXCHANGE_PEER_COPY)
     if stage == 4 and band != 0:
         pytest.skip("the solve runs on the first device only")
@@ -90,7 +142,7 @@ def test_cli_row_bands(G, scene_tmp, tmp_path):
     xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=64, height=64)
     exe = os.path.join(ROOT, "gradient-based-path-tracing_amd", "lajolla")
     one, two = tmp_path / "one.pfm", tmp_path / "two.pfm"
-    r1 = subprocess.run([exe, "-o", str(one), "--spp", "4", xml], capture_output=True, text=True, timeout=300)
+    r1 = subprocess.run([exe, "-o", str(one), "--spp", "4", "--plan-rows", "32", xml], capture_output=True, text=True, timeout=300)   # work items cut as for the two 32-row bands
     r2 = subprocess.run([exe, "-o", str(two), "--spp", "4", "--devices", "0,0", "--exchange", "peer", xml], capture_output=True, text=True, timeout=300)
     assert r1.returncode == 0 and r2.returncode == 0, r1.stderr + r2.stderr
     assert "2 row bands (peer copies)" in r2.stdout
@@ -111,7 +163,7 @@ def _bench(*extra):
 def test_bench_two_ranks_rehearsal_equals_one_rank(G):
     """`python bench.py --gpus 2` as typed (self-launching), both ranks on this box's one GPU over gloo: same strong-scaling
     image as the single-rank run, hash for hash."""
-    one = _bench()
+    one = _bench("--plan-bands", "2")          # one rank, work items cut as for two bands: the image two ranks produce
     two = _bench("--gpus", "2", "--dist-backend", "gloo")
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and "rehearsal" in two and "rehearsal" not in one
     assert two["scaling"] == "weak" and two["config"]["workload"].count("8 spp total")

@@ -143,8 +143,11 @@ def test_jpeg_decoder_matches_the_reference_decoder(G):
 def test_jpeg_decoder_rejects_what_it_does_not_decode(G, tmp_path):
     import pytest
     p = tmp_path / "bad.jpg"
-    p.write_bytes(b"\xff\xd8\xff\xc2\x00\x0b\x08\x00\x10\x00\x10\x01\x01\x11\x00")     # SOF2: progressive
-    with pytest.raises(G.GdptError, match="progressive"):
+    p.write_bytes(b"\xff\xd8\xff\xc9\x00\x0b\x08\x00\x10\x00\x10\x01\x01\x11\x00\xff\xd9")     # SOF9: arithmetic coding (stb_image refuses it too)
+    with pytest.raises(G.GdptError):
+        G.imread(str(p), 3)
+    p.write_bytes(b"\xff\xd8\xff\xc2\x00\x0b\x08\x00\x10\x00\x10\x01\x01\x11\x00\xff\xd9")     # SOF2 without a scan
+    with pytest.raises(G.GdptError, match="without image data"):
         G.imread(str(p), 3)
     p.write_bytes(b"not a jpeg")
     with pytest.raises(G.GdptError):
@@ -202,8 +205,8 @@ def test_gdtex_companion_rejects_lying_headers(G, tmp_path):
     good2 = b"GDTEX2\n" + struct.pack("<iiiI", 4, 3, 3, len(z)) + z
     good1 = b"GDTEX1\n" + struct.pack("<iii", 4, 3, 3) + tex.astype(np.float32).tobytes()
     for blob in (good1, good2):
-        p = tmp_path / "t.png"                      # unknown suffix -> the loader looks for the companion
-        (tmp_path / "t.png.gdtex").write_bytes(blob)
+        p = tmp_path / "t.tga"                      # a format without a native decoder -> the loader looks for the companion
+        (tmp_path / "t.tga.gdtex").write_bytes(blob)
         a = G.imread(str(p), 3)
         assert a.shape == (3, 4, 3)
     expect = np.float32(tex / np.float32(255.0)) ** np.float32(2.2)
@@ -217,6 +220,49 @@ def test_gdtex_companion_rejects_lying_headers(G, tmp_path):
         good1[:-5],
     ]
     for blob in bad:
-        (tmp_path / "t.png.gdtex").write_bytes(blob)
+        (tmp_path / "t.tga.gdtex").write_bytes(blob)
         with pytest.raises(G.GdptError):
-            G.imread(str(tmp_path / "t.png"), 3)
+            G.imread(str(tmp_path / "t.tga"), 3)
+
+
+def test_png_and_progressive_jpeg_decoders_match_the_reference_decoder(G):
+    """tests/golden/images (made by tests/golden/make_images.py: PNGs of every colour type, bit depth 1..16, all five scanline
+    filters, Adam7, palettes, tRNS; progressive JPEGs at 4:2:0 / 4:2:2 / 4:4:4 / grey) through the build's own decoders ==
+    what the reference's imread3 / imread1 (stb_image v2.27 as vendored there) return: CRC-32 of the fp32 texels,
+    generated by oracle/ref_img.cpp from the reference's own src/image.cpp."""
+    import os
+    import zlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    gold = _golden()
+    assert len(gold["fixtures_imread3"]) >= 30
+    kinds = set()
+    for name, rec in gold["fixtures_imread3"].items():
+        path = os.path.join(here, "golden", "images", name)
+        a = G.imread(path, 3)
+        assert a.shape == (rec["height"], rec["width"], 3), name
+        assert zlib.crc32(a.astype(np.float32).tobytes()) == rec["crc32"], name
+        a1 = G.imread(path, 1)
+        assert zlib.crc32(a1.astype(np.float32).tobytes()) == gold["fixtures_imread1"][name]["crc32"], name
+        kinds.add(name.split(".")[-1])
+    assert kinds == {"png", "jpg"}
+
+
+def test_corrupt_png_and_jpeg_are_errors_not_crashes(G, tmp_path):
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    rng = np.random.default_rng(3)
+    for name in ("rgba16_adam7.png", "palette4_adam7.png", "grey2.png", "prog_420.jpg", "prog_big_q35.jpg"):
+        raw = bytearray(open(os.path.join(here, "golden", "images", name), "rb").read())
+        for trial in range(60):
+            b = bytearray(raw)
+            for _ in range(1 + trial % 4):
+                b[int(rng.integers(8, len(b)))] = int(rng.integers(0, 256))
+            if trial % 7 == 0:
+                b = b[: int(rng.integers(10, len(b)))]
+            p = tmp_path / ("m_" + name)
+            p.write_bytes(bytes(b))
+            try:
+                a = G.imread(str(p), 3)
+                assert a.ndim == 3 and a.shape[2] == 3
+            except G.GdptError:
+                pass

@@ -6,7 +6,8 @@ has no collective inside; exchange and solve are priced separately in DESIGN.md 
 
 For each N: per-band ms, max / mean, and the strong-scaling efficiency the imbalance alone implies
 (one-GPU time / (N * slowest band)). Output: profiles/r03_band_costs.txt (via gpurun_out/).
-usage: time_bands.py [--balanced]      --balanced: bands from sharding.band_rows_weighted (cost-balanced), if present"""
+Work items are cut for the largest band of the sharding (GdptRenderParams.plan_rows), as the multi-device hosts do; bands
+of equal tile-row count and bands of equal pilot cost (Scene.tile_row_costs -> sharding.bands_weighted) side by side."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,24 +16,26 @@ from gdpt_amd import sharding
 from helpers import scene_variant
 import tempfile
 tmp = tempfile.mkdtemp()
-for name, size, spp in (("C2' cbox 512x512x256", 512, 256), ("C3 cbox 1024x1024x256", 1024, 256)):
+for name, size, spp in (("C2' cbox 512x512x256", 512, 256), ("C3 cbox 1024x1024x256", 1024, 256), ("weak-scaling unit: cbox 512x512, 16 spp per GPU", 512, 16)):
     sc = G.Scene(G.parse_scene(scene_variant(tmp, "cbox/cbox_gdpt.xml", width=size, height=size)))
-    def cost(rows):
+    weak = spp == 16
+    def cost(rows, plan_rows, spp_=spp):
         best = 1e9
         for _ in range(3):
-            _, st = sc.render(spp, G.RNG_SAMPLE, rows=rows)
+            _, st = sc.render(spp_, G.RNG_SAMPLE, rows=rows, plan_rows=plan_rows)
             best = min(best, st.render_ms)
         return best
-    whole = cost((0, size))
+    whole = cost((0, size), 0)
     print(f"{name}: one GPU, whole film: {whole:.2f} ms = {size * size * spp / whole / 1e3:.0f} Msamples/s", flush=True)
-    # per tile row (16 pixel rows): the finest unit a band boundary can move by
-    tile_rows = size // 16
-    per_tile_row = [cost((t * 16, (t + 1) * 16)) for t in range(tile_rows)] if size == 512 else None
-    if per_tile_row:
-        print("   tile-row costs (ms): " + " ".join(f"{c:.2f}" for c in per_tile_row), flush=True)
+    pilot = sc.tile_row_costs()
+    print("   pilot (rays per tile row at 1 spp, relative to the mean): " + " ".join(f"{c / (sum(pilot) / len(pilot)):.2f}" for c in pilot), flush=True)
     for n in (2, 4, 8):
-        bands = sharding.all_bands(size, n)
-        ms = [cost(b) for b in bands]
-        mean = sum(ms) / n
-        print(f"   N={n}: bands of {bands[0][1] - bands[0][0]} rows: " + " ".join(f"{m:.2f}" for m in ms) +
-              f" ms | max/mean {max(ms) / mean:.3f} | sum/whole {sum(ms) / whole:.3f} | strong-scaling efficiency of the render {whole / (n * max(ms)):.3f}", flush=True)
+        for label, bands in (("equal tile rows", sharding.all_bands(size, n)), ("equal pilot cost", sharding.bands_weighted(size, n, pilot))):
+            plan = max(b[1] - b[0] for b in bands)
+            k = n if weak else 1                       # weak scaling: 16 spp per GPU = 16 N spp on the band
+            ms = [cost(b, plan, spp * k) for b in bands]
+            film_plan = [cost(b, 0, spp * k) for b in bands[:1]][0] if label == "equal tile rows" else None
+            mean = sum(ms) / n
+            print(f"   N={n} {label:16s} rows " + " ".join(str(b[1] - b[0]) for b in bands) + ": " + " ".join(f"{m:.2f}" for m in ms) +
+                  f" ms | max/mean {max(ms) / mean:.3f} | efficiency of the render (one-GPU time / ({'1' if weak else 'N'} x slowest band)) {whole / ((1 if weak else n) * max(ms)):.3f}" +
+                  (f" | band 0 with the work items cut for the whole film (round 2): {film_plan:.2f} ms" if film_plan else ""), flush=True)
