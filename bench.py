@@ -365,7 +365,7 @@ def run_rank(args):
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": f"scene file shipped with the reference ({scene_rel}); PCG32 stream per sample, seeded as src/pcg.h",
         "config": {"workload": f"{scene_rel} Integrator::GradPath {W}x{H}, {args.spp} spp per GPU "
-                               f"({spp_total} spp total), render+assemble+Poisson(DCT-I as fp64 GEMM) per step"
+                               f"({spp_total} spp total), render+assemble+Poisson(DCT-I as folded fp64 MFMA GEMMs, own kernels) per step"
                                + (" [shift=reconnect: extension mode, NOT the headline workload]" if args.shift == "reconnect" else ""),
                    "rng": "sample-stream PCG32",
                    "sharding": (f"{world} row bands ({'equal measured cost: rows ' + ' '.join(str(b[1] - b[0]) for b in bands) if tile_costs is not None else 'equal tile-row counts'}), "
@@ -502,6 +502,14 @@ def _kernel_lines(got, W, H, spp, pmc):
     add("assemble_kernel", "gp::assemble_kernel", 8 * 8.0 * n3)            # 5 reads + 3 writes per unknown
     add("dct_rhs_kernel", "gp::dct_rhs_kernel", 4 * 8.0 * n3)              # read c, cx, cy; write h
     for k, t in got["times"].items():
+        if "dct_fold_gemm_f64" in k:          # own kernels: two row passes (X*Cw) + two column passes (Ch^T*T) per step, all under one name
+            nominal = 2.0 * 3 * (W * W * H + H * H * W) / 2          # flops of one UNFOLDED pass, mean of the two shapes
+            ach = nominal / (t["avg_us"] * 1e-6) / 1e12
+            lines.append({"kernel": "gp::dct_fold_gemm_f64 (4 launches per step: 2 row + 2 column passes; even/odd fold = half the flops of the plain product)",
+                          "launches_per_step": 4, "avg_us": t["avg_us"], "bound": "mfma", "unit": "TFLOP/s", "peak": pmc.VECTOR_FP64_PEAK_TFLOPS,
+                          "achieved": ach / 2, "frac": ach / 2 / pmc.VECTOR_FP64_PEAK_TFLOPS,
+                          "achieved_counting_the_unfolded_product": ach, "frac_counting_the_unfolded_product": ach / pmc.VECTOR_FP64_PEAK_TFLOPS,
+                          "traffic": pmc.hbm_bytes(_find(got["counters"], k) or {})})
         if k.startswith("Cijk_"):                                          # rows: X*Cw (2*W*W*H flop per channel); columns: Ch^T*T (2*H*H*W)
             fl = 2.0 * 3 * (W * W * H if "Ailk_Bljk" in k else H * H * W)
             ach = fl / (t["avg_us"] * 1e-6) / 1e12

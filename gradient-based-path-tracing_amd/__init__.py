@@ -226,7 +226,7 @@ class Scene:
             pass
 
 
-def fourierSolve(width, height, imgData, imgGradX, imgGradY, dataCost=0.04, solver=defs.SOLVER_DCT, tol=0.0,
+def fourierSolve(width, height, imgData, imgGradX, imgGradY, dataCost=0.04, solver=defs.SOLVER_DEFAULT, tol=0.0,
                  max_iters=0, return_stats=False):
     """Screened-Poisson reconstruction on the GPU; arguments as the reference's fourierSolve
     (src/render.cpp:172-175). Inputs HxWx3 (or flat W*H*3) float64; returns HxWx3."""
@@ -298,7 +298,7 @@ class MultiScene:
             pass
 
 
-def poisson_solve_device(width, height, c_ptr, gx_ptr, gy_ptr, out_ptr, alpha=0.04, solver=defs.SOLVER_DCT, tol=0.0,
+def poisson_solve_device(width, height, c_ptr, gx_ptr, gy_ptr, out_ptr, alpha=0.04, solver=defs.SOLVER_DEFAULT, tol=0.0,
                          max_iters=0, stream=None, want_stats=False):
     st = defs.GdptPoissonStats() if want_stats else None
     _check(lib().gdpt_poisson_solve_device(int(width), int(height), C.c_void_p(int(c_ptr)), C.c_void_p(int(gx_ptr)),
@@ -402,7 +402,7 @@ class debug_knobs:
         """GDPT_FORCE_EAGER=1 -> force_eager=1 ... for the manual sweep scripts (tests/sweep_*.py, tune_render.py)."""
         environ = os.environ if environ is None else environ
         names = ("force_eager", "log2k", "keep_frac", "search_frac", "blocks_per_cu", "no_lds_scene", "lds_wide",
-                 "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "stamps", "wavefront", "wf_slots", "wf_sort", "multi_fail_band", "multi_fail_stage", "full_material_switch", "no_plain_kernel", "replay_per_step")
+                 "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "stamps", "wavefront", "wf_slots", "wf_sort", "multi_fail_band", "multi_fail_stage", "dct_bk", "full_material_switch", "no_plain_kernel", "replay_per_step")
         lib().gdpt_debug_knobs_reset()
         for n in names:
             v = environ.get("GDPT_" + n.upper())

@@ -12,6 +12,7 @@ INTEGRATOR_PATH, INTEGRATOR_GRADPATH, INTEGRATOR_OTHER = 5, 7, -1
 RNG_TILE, RNG_SAMPLE = 0, 2
 SHIFT_REFERENCE, SHIFT_RECONNECT = 0, 1
 SOLVER_CG, SOLVER_DCT, SOLVER_DCT_MFMA = 0, 1, 2
+SOLVER_DEFAULT = SOLVER_DCT_MFMA      # GDPT_SOLVER_DEFAULT (include/gdpt.h)
 
 
 class GdptTexture(C.Structure):

@@ -25,7 +25,7 @@ namespace {
 std::mutex g_knob_mu;
 std::map<std::string, double> g_knobs;     // test-only overrides, include/gdpt_debug.h
 const char *const kKnobNames[] = {"force_eager", "log2k", "keep_frac", "search_frac", "blocks_per_cu", "no_lds_scene", "lds_wide",
-                                  "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "stamps", "wavefront", "wf_slots", "wf_sort", "multi_fail_band", "multi_fail_stage", "full_material_switch", "no_plain_kernel", "replay_per_step"};
+                                  "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "stamps", "wavefront", "wf_slots", "wf_sort", "multi_fail_band", "multi_fail_stage", "dct_bk", "full_material_switch", "no_plain_kernel", "replay_per_step"};
 double g_stamps[16] = {0};
 } // namespace
 void debug_store_stamps(const unsigned long long *v, int n) {
@@ -188,6 +188,25 @@ int gdpt_bvh_check(const float *bounds6, int n, int32_t stats[8]) {
         }
         for (int i = 0; i < n; i++) if (seenw[i] != 1) throw std::runtime_error("gdpt_bvh_check: a primitive is not in exactly one wide leaf");
         stats[5] = leaves_keep; stats[6] = max_keep;
+        // quantised BVH4 (DevBvh4QNode, what the kernels walk from HBM): same topology; the grid box of a child, evaluated exactly
+        // in double, encloses the fp32 box it replaces (and with it the whole subtree)
+        {
+            const std::vector<DevBvh4QNode> q4 = gdpt::quantise_bvh4(wide.nodes);
+            if (q4.size() != wide.nodes.size()) throw std::runtime_error("gdpt_bvh_check: quantised BVH4 has another node count");
+            for (size_t i = 0; i < q4.size(); i++) {
+                const DevBvh4QNode &nd = q4[i];
+                for (int k = 0; k < 3; k++) if (!(nd.scale[k] >= 0x1p-60f) || !std::isfinite(nd.scale[k])) throw std::runtime_error("gdpt_bvh_check: quantised BVH4 grid step out of range");
+                for (int c = 0; c < 4; c++) {
+                    if (nd.child[c] != wide.nodes[i].child[c]) throw std::runtime_error("gdpt_bvh_check: quantised BVH4 child differs");
+                    if (nd.child[c] == GDPT_CHILD_EMPTY) continue;
+                    for (int k = 0; k < 3; k++) {
+                        if (!(wide.nodes[i].lo[k][c] <= wide.nodes[i].hi[k][c])) continue;
+                        const double lo = (double)nd.org[k] + (double)nd.qlo[k][c] * (double)nd.scale[k], hi = (double)nd.org[k] + (double)nd.qhi[k][c] * (double)nd.scale[k];
+                        if (!(lo <= (double)wide.nodes[i].lo[k][c] && (double)wide.nodes[i].hi[k][c] <= hi)) throw std::runtime_error("gdpt_bvh_check: quantised BVH4 grid box does not enclose the fp32 box");
+                    }
+                }
+            }
+        }
         // 8-wide quantised form: the grid box of a child (evaluated exactly, in double) encloses its whole subtree
         {
             const std::vector<DevBvh8Node> &n8 = wide.nodes8;

@@ -69,7 +69,7 @@ struct DevBvh4QNode {
     int32_t child[4];
 };
 #ifndef GDPT_HBM_Q4
-#define GDPT_HBM_Q4 0              // 1: scenes walked from HBM use DevBvh4QNode
+#define GDPT_HBM_Q4 1              // scenes walked from HBM use DevBvh4QNode (0: the fp32 DevBvh4Node, A/B builds)
 #endif
 
 // Traversal record of one primitive, 48 B, in BVH leaf order.

@@ -18,6 +18,7 @@
 //   cg_step_b: x += a p', r -= a q, partial <r,r>
 // Scalars are reduced from per-block partials by every block in the same fixed order (deterministic).
 #include "poisson_kernels.h"
+#include "../capi_common.h"
 #include "../../../include/gdpt.h"
 
 #include <rocblas/rocblas.h>
@@ -274,16 +275,24 @@ __global__ __launch_bounds__(kBlock) void dct_finalize_kernel(Geo g, const doubl
 //   FORM 0 (row pass,    T = X * Cw):    C[m][2q+p] = sum_x (X[m][x] +- X[m][K-1-x]) * E_p[x][q]      data operand = A, folded along its rows
 //   FORM 1 (column pass, Y = Ch^T * T):  C[2q+p][n] = sum_y E_p^T[q][y] * (X[y][n] +- X[K-1-y][n])    data operand = B, folded along its columns
 // Block = 8 waves (two per SIMD: one wave's LDS traffic and waits sit under the other's MFMAs), block tile 64 x 64 of one
-// (channel, parity) pair in blockIdx.z, K step 16 staged through LDS, double-buffered: while the MFMAs of step s run, the
-// global loads of step s+1 are in flight and land in the other buffer. LDS images: A tile row-major [64][18] (the MFMA's A
-// lanes read [row l&15][k l>>4]: 36 m + 2 k dwords, conflict-free within each half wave), B tile k-major [16][80]
-// ([k l>>4][col l&15]: the two k rows of a half wave sit 32 banks apart). A wave owns 16 x 32 = two MFMA tiles; result
+// (channel, parity) pair, K step BK staged through double-buffered LDS. Two shapes of the same loop, picked by the host:
+//   BK = 32, global loads TWO steps ahead in a ring of two register groups, 76 KB of LDS (2 blocks per CU): for grids of at
+//           most two blocks per CU (512 x 512: 192 blocks), where nothing but the block itself can hide a load from L2 / the
+//           Infinity Cache (a 16-deep step is 8 MFMAs = 512 cycles per wave; with loads one such step ahead the 512 x 512 solve
+//           took 103 us, the same as the library, with this shape 93);
+//   BK = 16, loads one step ahead, 39 KB of LDS and 61 VGPRs (4 blocks = 32 waves per CU): for larger grids, where the other
+//           resident blocks cover the loads (1024 x 1024: 352 us against 373-383 with the deep shape).
+// LDS images: A tile row-major [64][BK + 1] (the MFMA's A lanes read [row l&15][k l>>4]), B tile k-major [BK][80]
+// ([k l>>4][col l&15]). The compiler fetches the operands with ds_read2_b64, which the LDS serves in groups of 16 lanes on 32
+// banks (MI355X_MICROARCH.md, LDS table): 16 rows of the A tile must therefore start on 16 different even banks, which an ODD
+// row stride gives (2 (BK+1) r mod 32 = 2 r) and the even stride of the first version did not (SQ_LDS_BANK_CONFLICT as many
+// cycles as SQ_ACTIVE_INST_LDS: every A read a two-way conflict, profiles/r03_poisson_pmc.txt). A wave owns 16 x 32 = two MFMA tiles; result
 // register r of lane l is C[(l>>4) + 4r][l&15] (the f64 map, not the f32 one).
 // Epilogues (EPI, column pass only): 0 plain; 1 the spectral division  F^ = H^ / (alpha - (float)(lapY[y] + lapX[x]))  with
 // the DC override F^[0,0] = sum(w u) (src/render.cpp:229-239: the block holding element (0,0) reduces the per-block partials
 // of dct_rhs_kernel itself); 2 the final  out[(y*W+x)*3+ch] = f / (4 (W-1)(H-1))  (:245-247), planar -> interleaved.
 // (History, whole 512x512x3 solve on MI355X: unfolded 64x64 tiles with 4 waves 132 us, rocBLAS dgemm_strided_batched 103 us.)
-constexpr int kGemmBM = 64, kGemmBN = 64, kGemmBK = 16, kGemmLdB = 80, kGemmLdA = 18, kGemmThreads = 512;
+constexpr int kGemmBM = 64, kGemmBN = 64, kGemmLdB = 80, kGemmThreads = 512;
 struct GemmEpi {
     double alpha; const double *lap_x, *lap_y;      // EPI 1
     const double *dc_partials; int dc_nb;            // EPI 1: [3][dc_nb] block partials of sum(w u)
@@ -292,79 +301,103 @@ struct GemmEpi {
 // M x N = extent of the output; K = length of the folded dimension (FORM 0: K == N, FORM 1: K == M); X = data operand with
 // row stride ldx and channel stride strideX; E0 / E1 = the parity tables (FORM 0: E_p, ceil(K/2) x ceil-or-floor(K/2);
 // FORM 1: E_p^T), row stride ldE each.
-template <int FORM, int EPI>
-__global__ __launch_bounds__(kGemmThreads, 2) void dct_fold_gemm_f64(int M, int N, int K, const double *X, int ldx, long long strideX,
+// Block -> tile, XCD-aware. A 64 x 64 tile of depth K/2 reads 5 flops per operand byte; with every block fetching its operand
+// panels from the Infinity Cache the four products of a 512 x 512 solve were bound by that traffic (75 MB per product, 21 us
+// against 7 us of MFMA time). The blocks that share a DATA panel — FORM 0: the same 64 rows of X (all column tiles, both
+// parities), FORM 1: the same 64 columns — are therefore given block ids that are equal modulo 8, which the hardware deals
+// to one XCD (MI355X_MICROARCH.md: workgroup dispatch; for speed only — nothing depends on it): the panel is fetched into
+// that XCD's L2 once and the other seven members hit there; the parity tables (1 MB at 512) end up in every L2.
+// Grid = 8 x ceil(groups / 8) x members blocks, 1-D; ids whose group does not exist return at once.
+template <int FORM, int EPI, int BK>
+__global__ __launch_bounds__(kGemmThreads, BK == 32 ? 2 : 4) void dct_fold_gemm_f64(int M, int N, int K, int tiles_m, int tiles_n, const double *X, int ldx, long long strideX,
                                                                      const double *E0, const double *E1, int ldE,
                                                                      double *C, int ldc, long long strideC, GemmEpi e) {
     typedef double d4 __attribute__((ext_vector_type(4)));
     typedef double d2 __attribute__((ext_vector_type(2)));
+    constexpr int kGemmBK = BK, kGemmLdA = BK + 1, H = BK / 16;      // H staging passes per step and thread; odd row stride, see below
     __shared__ __attribute__((aligned(16))) double sA[2][kGemmBM * kGemmLdA];
     __shared__ __attribute__((aligned(16))) double sB[2][kGemmBK * kGemmLdB];
     __shared__ double red[kBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ch = blockIdx.z >> 1, p = blockIdx.z & 1;
+    int ch, p, tile_m, tile_n;
+    {
+        const int b = (int)blockIdx.x, xcd = b & 7, j = b >> 3;
+        const int shared_tiles = FORM == 0 ? tiles_m : tiles_n, other_tiles = FORM == 0 ? tiles_n : tiles_m;
+        const int members = other_tiles * 2, groups = shared_tiles * 3;
+        const int t = j / members, mem = j - t * members;
+        const int g = xcd + 8 * t;
+        if (g >= groups) return;                             // (block-uniform)
+        ch = g / shared_tiles;
+        const int st = g - ch * shared_tiles;
+        p = mem / other_tiles;
+        const int ot = mem - p * other_tiles;
+        tile_m = FORM == 0 ? st : ot; tile_n = FORM == 0 ? ot : st;
+    }
     X += (long long)ch * strideX; C += (long long)ch * strideC;
     const double *E = p ? E1 : E0;
     const int Kf = (K + 1) >> 1;                         // folded depth
     const int mid = (K & 1) ? (K >> 1) : -1;             // the self-paired sample of an odd length
     const int Qn = (K + 1 - p) >> 1;                     // outputs of this parity along the folded dimension
     const int Mt = FORM == 0 ? M : Qn, Nt = FORM == 0 ? Qn : N;     // extent of this block's (parity-compact) output index space
-    const int m0 = blockIdx.y * kGemmBM, n0 = blockIdx.x * kGemmBN;
+    const int m0 = tile_m * kGemmBM, n0 = tile_n * kGemmBN;
     if (m0 >= Mt || n0 >= Nt) return;                    // (block-uniform: the odd parity has one output less)
     const int wm = (wave >> 1) * 16, wn = (wave & 1) * 32;
-    // staging roles: A tile 64 x 16 -> thread (row tid >> 3, 2 consecutive k); B tile 16 x 64 -> thread (k = tid >> 5, 2 consecutive n)
+    // staging roles, two passes per step: A tile 64 x 32 -> thread (row tid >> 3, k = 2 (tid & 7) + 16 pass, 2 consecutive k);
+    // B tile 32 x 64 -> thread (k = (tid >> 5) + 16 pass, 2 consecutive n)
     const int am = tid >> 3, ak = (tid & 7) * 2;
     const int bk = tid >> 5, bn = (tid & 31) * 2;
     const double sgn = p ? -1.0 : 1.0;
     // vector loads when every 16-byte pair is aligned and the tile lies inside the matrices (block-uniform)
     const bool fast = ((ldx | ldE | K) & 1) == 0 && m0 + kGemmBM <= Mt && n0 + kGemmBN <= Nt &&
                       ((reinterpret_cast<unsigned long long>(X) | reinterpret_cast<unsigned long long>(E)) & 15ull) == 0;
-    d2 ra, rb;
     auto fold = [&](double a, double b, int x) { return (x == mid) ? (p ? 0.0 : a) : a + sgn * b; };
-    auto fetch = [&](int k0) {
-        if (fast && k0 + kGemmBK <= Kf) {                 // (K even here: no middle sample)
-            if (FORM == 0) {
-                const double *row = X + (long long)(m0 + am) * ldx;
-                const d2 a = *reinterpret_cast<const d2 *>(row + k0 + ak), b = *reinterpret_cast<const d2 *>(row + K - 2 - (k0 + ak));   // b = (X[K-2-x], X[K-1-x])
-                ra = d2{a.x + sgn * b.y, a.y + sgn * b.x};
-                rb = *reinterpret_cast<const d2 *>(E + (long long)(k0 + bk) * ldE + n0 + bn);
-            } else {
-                ra = *reinterpret_cast<const d2 *>(E + (long long)(m0 + am) * ldE + k0 + ak);
-                const d2 a = *reinterpret_cast<const d2 *>(X + (long long)(k0 + bk) * ldx + n0 + bn), b = *reinterpret_cast<const d2 *>(X + (long long)(K - 1 - (k0 + bk)) * ldx + n0 + bn);
-                rb = d2{a.x + sgn * b.x, a.y + sgn * b.y};
-            }
-            return;
-        }
+    struct Group { d2 a[H], b[H]; };                     // one K step of this thread: H (A, B) pairs
+    auto fetch = [&](int k0, Group &g) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int gm = m0 + am, ka = k0 + ak + j, gk = k0 + bk, gn = n0 + bn + j;
-            if (FORM == 0) {
-                ra[j] = (gm < Mt && ka < Kf) ? fold(X[(long long)gm * ldx + ka], X[(long long)gm * ldx + (K - 1 - ka)], ka) : 0.0;
-                rb[j] = (gk < Kf && gn < Nt) ? E[(long long)gk * ldE + gn] : 0.0;
-            } else {
-                ra[j] = (gm < Mt && ka < Kf) ? E[(long long)gm * ldE + ka] : 0.0;
-                rb[j] = (gk < Kf && gn < Nt) ? fold(X[(long long)gk * ldx + gn], X[(long long)(K - 1 - gk) * ldx + gn], gk) : 0.0;
+        for (int h = 0; h < H; h++) {
+            const int ka0 = k0 + ak + 16 * h, kb = k0 + bk + 16 * h;
+            if (fast && k0 + kGemmBK <= Kf) {             // (K even here: no middle sample)
+                if (FORM == 0) {
+                    const double *row = X + (long long)(m0 + am) * ldx;
+                    const d2 u = *reinterpret_cast<const d2 *>(row + ka0), v = *reinterpret_cast<const d2 *>(row + K - 2 - ka0);   // v = (X[K-2-x], X[K-1-x])
+                    g.a[h] = d2{u.x + sgn * v.y, u.y + sgn * v.x};
+                    g.b[h] = *reinterpret_cast<const d2 *>(E + (long long)kb * ldE + n0 + bn);
+                } else {
+                    g.a[h] = *reinterpret_cast<const d2 *>(E + (long long)(m0 + am) * ldE + ka0);
+                    const d2 u = *reinterpret_cast<const d2 *>(X + (long long)kb * ldx + n0 + bn), v = *reinterpret_cast<const d2 *>(X + (long long)(K - 1 - kb) * ldx + n0 + bn);
+                    g.b[h] = d2{u.x + sgn * v.x, u.y + sgn * v.y};
+                }
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int gm = m0 + am, ka = ka0 + j, gn = n0 + bn + j;
+                if (FORM == 0) {
+                    g.a[h][j] = (gm < Mt && ka < Kf) ? fold(X[(long long)gm * ldx + ka], X[(long long)gm * ldx + (K - 1 - ka)], ka) : 0.0;
+                    g.b[h][j] = (kb < Kf && gn < Nt) ? E[(long long)kb * ldE + gn] : 0.0;
+                } else {
+                    g.a[h][j] = (gm < Mt && ka < Kf) ? E[(long long)gm * ldE + ka] : 0.0;
+                    g.b[h][j] = (kb < Kf && gn < Nt) ? fold(X[(long long)kb * ldx + gn], X[(long long)(K - 1 - kb) * ldx + gn], kb) : 0.0;
+                }
             }
         }
     };
-    auto stage = [&](int buf) {
-        *reinterpret_cast<d2 *>(&sA[buf][am * kGemmLdA + ak]) = ra;      // 144 am + 16 (tid & 7) bytes: 16-byte aligned
-        *reinterpret_cast<d2 *>(&sB[buf][bk * kGemmLdB + bn]) = rb;
+    auto stage = [&](int buf, const Group &g) {
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+            sA[buf][am * kGemmLdA + ak + 16 * h] = g.a[h].x; sA[buf][am * kGemmLdA + ak + 16 * h + 1] = g.a[h].y;      // (rows are only 8-byte aligned)
+            *reinterpret_cast<d2 *>(&sB[buf][(bk + 16 * h) * kGemmLdB + bn]) = g.b[h];
+        }
     };
     d4 acc[2];
     acc[0] = d4{0.0, 0.0, 0.0, 0.0}; acc[1] = d4{0.0, 0.0, 0.0, 0.0};
     const int steps = (Kf + kGemmBK - 1) / kGemmBK;
-    fetch(0);
-    stage(0);
-    __syncthreads();
-    for (int s = 0; s < steps; s++) {
-        const int buf = s & 1;
-        if (s + 1 < steps) fetch((s + 1) * kGemmBK);               // in flight during the MFMAs below
+    auto compute = [&](int buf) {
         const double *pa = sA[buf] + (wm + (lane & 15)) * kGemmLdA + (lane >> 4);
         const double *pb = sB[buf] + (lane >> 4) * kGemmLdB + wn + (lane & 15);
         double a[kGemmBK / 4], b0[kGemmBK / 4], b1[kGemmBK / 4];
 #pragma unroll
-        for (int ks = 0; ks < kGemmBK / 4; ks++) {                 // all operand reads of the step first: one LDS latency, not four
+        for (int ks = 0; ks < kGemmBK / 4; ks++) {                 // all operand reads of the step first: one LDS latency, not eight
             a[ks] = pa[ks * 4];
             b0[ks] = pb[ks * 4 * kGemmLdB]; b1[ks] = pb[ks * 4 * kGemmLdB + 16];
         }
@@ -373,8 +406,35 @@ __global__ __launch_bounds__(kGemmThreads, 2) void dct_fold_gemm_f64(int M, int 
             acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b0[ks], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b1[ks], acc[1], 0, 0, 0);
         }
-        if (s + 1 < steps) stage(buf ^ 1);
+    };
+    Group g0, g1;
+    if (BK == 32) {
+        // step s computes from LDS buffer s & 1, which was filled from register group s & 1; group s & 1 is refilled with step
+        // s + 2 as soon as it has been staged, i.e. two whole steps before it is needed again
+        fetch(0, g0);
+        if (steps > 1) fetch(kGemmBK, g1);
+        stage(0, g0);
+        if (steps > 2) fetch(2 * kGemmBK, g0);
         __syncthreads();
+        for (int s = 0; s < steps; s += 2) {
+            compute(0);
+            if (s + 1 < steps) { stage(1, g1); if (s + 3 < steps) fetch((s + 3) * kGemmBK, g1); }
+            __syncthreads();
+            if (s + 1 >= steps) break;
+            compute(1);
+            if (s + 2 < steps) { stage(0, g0); if (s + 4 < steps) fetch((s + 4) * kGemmBK, g0); }
+            __syncthreads();
+        }
+    } else {
+        fetch(0, g0);
+        stage(0, g0);
+        __syncthreads();
+        for (int s = 0; s < steps; s++) {
+            if (s + 1 < steps) fetch((s + 1) * kGemmBK, g0);          // in flight during the MFMAs below
+            compute(s & 1);
+            if (s + 1 < steps) stage((s & 1) ^ 1, g0);
+            __syncthreads();
+        }
     }
     double dc = 0.0;
     if (EPI == 1 && p == 0 && m0 == 0 && n0 == 0) {                // block-uniform branch: this block holds element (0,0)
@@ -626,13 +686,28 @@ PoissonResult poisson_dct(int dev, DctWorkspace &ws, int w, int h, const double 
         e.denom = 4.0 * (double)(w - 1) * (double)(h - 1); e.out = d_out; e.out_w = w;
         const int qw = (w + 1) / 2, qh = (h + 1) / 2;           // outputs of the even parity along the folded dimension
         const dim3 block(gp::kGemmThreads);
-        const dim3 grid_rows((unsigned)((qw + gp::kGemmBN - 1) / gp::kGemmBN), (unsigned)((h + gp::kGemmBM - 1) / gp::kGemmBM), 6);
-        const dim3 grid_cols((unsigned)((w + gp::kGemmBN - 1) / gp::kGemmBN), (unsigned)((qh + gp::kGemmBM - 1) / gp::kGemmBM), 6);
+        // tile counts of the parity-compact index spaces (even parity: the larger one), 1-D XCD-aware grids (dct_fold_gemm_f64)
+        const int tm_rows = (h + gp::kGemmBM - 1) / gp::kGemmBM, tn_rows = (qw + gp::kGemmBN - 1) / gp::kGemmBN;     // row pass: M = h, N' = ceil(w/2)
+        const int tm_cols = (qh + gp::kGemmBM - 1) / gp::kGemmBM, tn_cols = (w + gp::kGemmBN - 1) / gp::kGemmBN;     // column pass: M' = ceil(h/2), N = w
+        const dim3 grid_rows((unsigned)(8 * ((tm_rows * 3 + 7) / 8) * (tn_rows * 2)));
+        const dim3 grid_cols((unsigned)(8 * ((tn_cols * 3 + 7) / 8) * (tm_cols * 2)));
         const long long pl = (long long)plane;
-        hipLaunchKernelGGL((gp::dct_fold_gemm_f64<0, 0>), grid_rows, block, 0, stream, h, w, w, (const double *)A, w, pl, Ew[0], Ew[1], ld_ew, B, w, pl, e);      // B = A * Cw
-        hipLaunchKernelGGL((gp::dct_fold_gemm_f64<1, 1>), grid_cols, block, 0, stream, h, w, h, (const double *)B, w, pl, EhT[0], EhT[1], ld_eht, A, w, pl, e);   // A = Ch^T * B, / (alpha - lambda), DC
-        hipLaunchKernelGGL((gp::dct_fold_gemm_f64<0, 0>), grid_rows, block, 0, stream, h, w, w, (const double *)A, w, pl, Ew[0], Ew[1], ld_ew, B, w, pl, e);      // B = A * Cw
-        hipLaunchKernelGGL((gp::dct_fold_gemm_f64<1, 2>), grid_cols, block, 0, stream, h, w, h, (const double *)B, w, pl, EhT[0], EhT[1], ld_eht, A, w, pl, e);   // out = Ch^T * B / denom
+        int num_cus = 256;
+        { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) num_cus = prop.multiProcessorCount; }
+        // few blocks per CU: the deep-prefetch shape; many: the small-footprint shape (dct_fold_gemm_f64); test knob dct_bk forces one
+        int bk = ((long long)tm_rows * tn_rows * 6 <= 2LL * num_cus) ? 32 : 16;
+        { const int forced = gdpt::debug_knob_int("dct_bk", 0); if (forced == 16 || forced == 32) bk = forced; }
+        if (bk == 32) {
+            hipLaunchKernelGGL((gp::dct_fold_gemm_f64<0, 0, 32>), grid_rows, block, 0, stream, h, w, w, tm_rows, tn_rows, (const double *)A, w, pl, Ew[0], Ew[1], ld_ew, B, w, pl, e);      // B = A * Cw
+            hipLaunchKernelGGL((gp::dct_fold_gemm_f64<1, 1, 32>), grid_cols, block, 0, stream, h, w, h, tm_cols, tn_cols, (const double *)B, w, pl, EhT[0], EhT[1], ld_eht, A, w, pl, e);   // A = Ch^T * B, / (alpha - lambda), DC
+            hipLaunchKernelGGL((gp::dct_fold_gemm_f64<0, 0, 32>), grid_rows, block, 0, stream, h, w, w, tm_rows, tn_rows, (const double *)A, w, pl, Ew[0], Ew[1], ld_ew, B, w, pl, e);      // B = A * Cw
+            hipLaunchKernelGGL((gp::dct_fold_gemm_f64<1, 2, 32>), grid_cols, block, 0, stream, h, w, h, tm_cols, tn_cols, (const double *)B, w, pl, EhT[0], EhT[1], ld_eht, A, w, pl, e);   // out = Ch^T * B / denom
+        } else {
+            hipLaunchKernelGGL((gp::dct_fold_gemm_f64<0, 0, 16>), grid_rows, block, 0, stream, h, w, w, tm_rows, tn_rows, (const double *)A, w, pl, Ew[0], Ew[1], ld_ew, B, w, pl, e);
+            hipLaunchKernelGGL((gp::dct_fold_gemm_f64<1, 1, 16>), grid_cols, block, 0, stream, h, w, h, tm_cols, tn_cols, (const double *)B, w, pl, EhT[0], EhT[1], ld_eht, A, w, pl, e);
+            hipLaunchKernelGGL((gp::dct_fold_gemm_f64<0, 0, 16>), grid_rows, block, 0, stream, h, w, w, tm_rows, tn_rows, (const double *)A, w, pl, Ew[0], Ew[1], ld_ew, B, w, pl, e);
+            hipLaunchKernelGGL((gp::dct_fold_gemm_f64<1, 2, 16>), grid_cols, block, 0, stream, h, w, h, tm_cols, tn_cols, (const double *)B, w, pl, EhT[0], EhT[1], ld_eht, A, w, pl, e);
+        }
     }
     ck(hipGetLastError(), "dct kernel launch");
     float ms = 0;

@@ -356,17 +356,8 @@ GD void trav_init(const DevSceneView &sv, Trav &tv, double tfar) {
     tv.best.gid = -1; tv.best.t = (float)tfar; tv.best.u = tv.best.v = 0; tv.best.ngx = tv.best.ngy = tv.best.ngz = 0;
     tv.sp = 0; tv.cur = (sv.num_nodes == 0) ? kTravDone : 0;
 }
-// (Tried: the top of the tree — the first 21 / 64 / 128 nodes in breadth-first order — kept in LDS by the kernels that walk the
-// tree from HBM, on the reasoning that every ray starts there and a CU's L1 holds 128 lines: sponza 390.7 vs 390.6
-// Msamples/s, disney_metal +-1 %. Those visits are not where the walk waits.)
-// (Tried: stack entries that carry the child's box entry distance in their upper 11 bits — truncated fp32 exponent and three
-// mantissa bits beside a 21-bit child id, so no extra LDS — and are dropped at POP time when a closer hit has been found
-// since the push, instead of being fetched and tested first. Bit-identical images, and 6 % slower on cbox, 12 % on sponza
-// and the Disney scenes: the near-to-far order leaves few such entries, and the pop becomes a divergent loop of
-// dependent LDS reads that the whole wave waits for.)
-// (Tried: the top of the stack in a register inside trav_run, so that a pop hands out a value that is already there and the LDS
-// read behind it refills the register off the critical path. Same bits, no spills, and 2-4 % slower on sponza and the Disney
-// scenes, 1-3 % on cbox: every push turns into a conditional store plus a move.)
+// (What was tried on this walk and dropped — top of the tree in LDS, distance-tagged stack entries, the top of the stack in a
+// register — is recorded with its measurements in DESIGN.md 7, "Tried and dropped".)
 // OVF: the tree's stack bound may exceed the LDS column (BVH8): slots from GDPT_BVH_MAX_DEPTH on live in the lane's private array.
 template <bool OVF = false>
 GD void trav_pop(const TraceCtx &tx, int &cur, int &sp, int *ovf = nullptr) {
@@ -504,8 +495,6 @@ GD void trav_run(const DevSceneView &sv, const TraceCtx &tx, D3 org, D3 dir, flo
                 }
             }
         } else if (cur >= 0) {
-            // (Tried: a node visit that ends in a leaf intersects it in the same trip — a mixed wave executes both blocks
-            // anyway. cbox 1844 / 1858 vs 1867 / 1853 Msamples/s in a same-box A/B: nothing.)
             if (tx.count) { tc.nodes++; if (wave_leader()) tc.node_trips++; }
             trav_node<TC::WIDE, TC::FLAT>(tx, oi, inv, tnear, best.t, cur, sp, tv.ovf);
         } else if (cur != kTravDone) {
@@ -625,9 +614,6 @@ struct Lane {
 // SERIAL_RNG: one PCG stream runs through consecutive samples (TILE scheme); otherwise each sample owns stream
 // `base + s` (SAMPLE scheme) and its sub-pixel / bounce-1 numbers are re-derived from it when an offset needs them.
 // PLAIN: device_trace.h (kPlainNoSpheres | kPlainConstTex): sphere / texture code is not compiled in.
-// (Tried: keeping the sample's sub-pixel and bounce-1 numbers in 10 VGPRs for the offsets instead of re-deriving them from
-// the sample's stream, for the kernels with register headroom: the compiler already shares the derivation between the
-// two places that need it — 36 of 2883 vector instructions less, no change in run time.)
 template <bool LAMBERT, bool SERIAL_RNG, class ACC, class STAMPS = Stamps<false>, int PLAIN = 0>
 GD int lane_consume(const DevSceneView &sv, const TraceCtx &tx, int max_depth, double spp, unsigned long long base,
                     Lane &L, Trav &tv, LanePriv &lp, ACC &acc, LaneCounters &lc, TraceCounters &tc, STAMPS *stp = nullptr) {
@@ -916,12 +902,7 @@ GD TraceCtx setup_trace(const DevSceneView &sv, unsigned char *s_scene, int *s_s
     }
     return tx;
 }
-// (Tried twice: a copy of the material table in LDS behind the stack for scenes walked from HBM — every texture / parameter
-// read of every BSDF call goes through that table. Chosen at run time the table pointer becomes a generic pointer and every
-// read a flat_load waiting on both counters: 5-10 % slower. Chosen at compile time (a kernel template flag, ds_read
-// confirmed in the ISA; only ~40 of the glass kernel's 420 global loads are table reads): still 2 % slower than leaving
-// the table in HBM / L1 on disney_glass — and 25 % slower when a fixed 12 KB array on top of a deep tree's stack leaves room
-// for one block per CU only. The table stays in HBM / L1; only the stack is sized from the tree's own bound.)
+// (A copy of the material table in LDS was tried twice and dropped: DESIGN.md 7, "Tried and dropped".)
 
 // Work items of the persistent kernels: item = chunk * num_slots + slot, slot = tile * 256 + pixel_in_tile, tiles = the
 // reference's 16x16 tiles of the band in row-major order (ragged edge tiles keep all 256 slots; their outside pixels

@@ -191,12 +191,13 @@ typedef struct GdptPoissonStats {
 
 /* CG: conjugate gradients on W(alpha I - L) f = W h + DC shift (matches the DCT solve to the CG tolerance; differs
  *     from the reference by its fp32-lambda quirk, ~3e-9).
- * DCT: direct solve, exact reference operator; the two 1-D DCT-I passes are plain fp64 GEMMs against fixed cosine matrices
- *     and run as rocBLAS dgemm_strided_batched (the default: 0.10 ms at 512x512).
- * DCT_MFMA: the same solve with the passes as hand-written fp64 MFMA GEMM kernels whose epilogues carry the spectral
- *     division, the DC override and the final scaling (5 launches instead of 8; 0.13 ms at 512x512 — DESIGN.md 4.2). */
+ * DCT_MFMA (the default): direct solve, exact reference operator. The two 1-D DCT-I passes are fp64 GEMMs against fixed
+ *     cosine matrices, run by hand-written fp64 MFMA kernels on HALF the flops (even / odd fold of the DCT-I matrix); their
+ *     epilogues carry the spectral division, the DC override and the final scaling (5 launches).
+ * DCT: the same solve with the passes as rocBLAS dgemm_strided_batched on the unfolded matrices (8 launches): kept as the
+ *     measured alternative (tests/time_poisson.py). */
 enum { GDPT_SOLVER_CG = 0, GDPT_SOLVER_DCT = 1, GDPT_SOLVER_DCT_MFMA = 2 };
-#define GDPT_SOLVER_DEFAULT GDPT_SOLVER_DCT   /* what gdpt_poisson_solve, gdpt_gradient_path_render and gdpt_multi_* use */
+#define GDPT_SOLVER_DEFAULT GDPT_SOLVER_DCT_MFMA   /* what gdpt_poisson_solve, gdpt_gradient_path_render and gdpt_multi_* use */
 
 typedef struct GdptScene GdptScene;   /* opaque: device-resident scene (BVH2 + BVH4, triangles, materials, textures) */
 
@@ -244,8 +245,8 @@ int gdpt_assemble_device(int width, int height,
                          double *d_c, double *d_cx, double *d_cy, void *stream);
 
 /* Screened Poisson reconstruction; same arguments as fourierSolve (src/render.cpp:172-175). Host pointers.
- * Uses GDPT_SOLVER_DCT: the reference's algorithm itself (DCT-I, fp32-rounded eigenvalue, DC override), the
- * transform evaluated as fp64 GEMMs on the GPU. */
+ * Uses GDPT_SOLVER_DEFAULT: the reference's algorithm itself (DCT-I, fp32-rounded eigenvalue, DC override), the
+ * transform evaluated as fp64 MFMA GEMMs on the GPU. */
 int gdpt_poisson_solve(int width, int height,
                        const double *imgData, const double *imgGradX, const double *imgGradY,
                        double dataCost, double *imgOut);
@@ -255,7 +256,7 @@ int gdpt_poisson_solve_ex(int width, int height,
                           double dataCost, double *imgOut,
                           int solver, double tol, int max_iters, GdptPoissonStats *stats /* nullable */);
 /* Device-pointer variant (inputs/outputs in HBM). The library keeps its scratch per (device, stream). With
- * GDPT_SOLVER_DCT and stats == NULL the call only enqueues work on `stream` (no event, no host wait); with stats it
+ * GDPT_SOLVER_DCT_MFMA / GDPT_SOLVER_DCT and stats == NULL the call only enqueues work on `stream` (no event, no host wait); with stats it
  * brackets the solve with HIP events and waits for it. GDPT_SOLVER_CG always waits (host-side convergence check). */
 int gdpt_poisson_solve_device(int width, int height,
                               const double *d_c, const double *d_gx, const double *d_gy,

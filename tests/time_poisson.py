@@ -10,8 +10,11 @@ for w, h in ((512, 512), (1024, 1024), (1280, 720)):
     c, gx, gy = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in lcg_fields(w, h, seed=1))
     out = torch.zeros_like(c)
     res = {}
-    for name, which in (("own_mfma", G.SOLVER_DCT_MFMA), ("rocblas", G.SOLVER_DCT)):
-        for _ in range(3):
+    for name, which in (("own_mfma", G.SOLVER_DCT_MFMA), ("own_bk16", G.SOLVER_DCT_MFMA), ("own_bk32", G.SOLVER_DCT_MFMA), ("rocblas", G.SOLVER_DCT)):
+        G.debug_knobs.reset()
+        if name.startswith("own_bk"):
+            G.debug_knobs.set(dct_bk=int(name[-2:]))
+        for _ in range(12):
             G.poisson_solve_device(w, h, c.data_ptr(), gx.data_ptr(), gy.data_ptr(), out.data_ptr(), solver=which)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -22,5 +25,6 @@ for w, h in ((512, 512), (1024, 1024), (1280, 720)):
         res[name] = (e0.elapsed_time(e1) / 20, out.clone())
     d = (res["own_mfma"][1] - res["rocblas"][1]).abs().max().item()
     fl = 4 * 3 * (2.0 * w * w * h + 2.0 * h * h * w) / 2
-    print(f"{w}x{h}: own MFMA {res['own_mfma'][0] * 1e3:.1f} us ({fl / res['own_mfma'][0] / 1e9:.1f} TFLOP/s), rocBLAS {res['rocblas'][0] * 1e3:.1f} us "
+    G.debug_knobs.reset()
+    print(f"{w}x{h}: own MFMA {res['own_mfma'][0] * 1e3:.1f} us ({fl / res['own_mfma'][0] / 1e9:.1f} TFLOP/s counting the unfolded product; shape BK16 {res['own_bk16'][0] * 1e3:.1f} us, BK32 {res['own_bk32'][0] * 1e3:.1f} us), rocBLAS {res['rocblas'][0] * 1e3:.1f} us "
           f"({fl / res['rocblas'][0] / 1e9:.1f} TFLOP/s), max abs diff {d:.2e}", flush=True)
