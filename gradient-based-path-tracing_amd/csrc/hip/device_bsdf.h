@@ -72,6 +72,12 @@ GD double tex1(const DevSceneView &sv, const GdptTexture &t, const Vertex &vx) {
     return tex3(sv, t, vx).x;
 }
 
+// (Measured and dropped, round 3: the general switch calling an out-of-line lookup for non-constant textures — pointers into
+// global memory and scalars in, three doubles out, the calling pattern of sphere_hit. The two-sided lane machine shrank from
+// 100 000 to 25 000 instructions and compiled five times faster, and rendered disney_glass 24 %, DisneyBSDF 16 % and
+// disney_metal 15 % SLOWER (same-box A/B, profiles/r03_ab_texture_call.txt): the checkerboard floor of those scenes takes the
+// call on every hit, and a call in the middle of a 256-VGPR step parks the live state in scratch. Code size is not what binds
+// these kernels.)
 // ---- helpers ------------------------------------------------------------------------------------
 GD D3 sample_cos_hemisphere(D2 r) { // src/material.cpp:4-11
     // phi = 2*pi*u: sincospi(2u) skips the large-argument reduction of sincos (the two differ by the rounding of phi)
@@ -300,6 +306,24 @@ GD double dg_pdf(const Ctx &c, const GdptTexture &rough, const GdptTexture &anis
     double sd = g.h_dot_in + g.eta * h_dot_out;
     return ((1 - g.F) * g.d_m * g.g_in * fabs(h_dot_out * g.h_dot_in)) / (fabs(dot(g.f.n, in)) * sd * sd);
 }
+// eval and pdf of one direction pair share everything but the base colour and the second masking term: evaluated together
+// (the callers always want both) the half vector, Fresnel term, D and G1 are formed once. Every value is produced by the
+// expression that dg_eval / dg_pdf use for it, so the two results are bit-identical to the separate calls.
+GD void dg_eval_pdf(const Ctx &c, const GdptTexture &base, const GdptTexture &rough, const GdptTexture &aniso, double eta, D3 in, D3 out, D3 &f, double &pdf) {
+    D3 bc = T3(c, base);
+    GlassTerms g = glass_terms(c, rough, aniso, eta, in, out);
+    double g_m = g.g_in * g.g_out;
+    if (g.reflect) {
+        f = bc * (g.F * g.d_m * g_m) / (4 * fabs(dot(g.f.n, in)));
+        pdf = (g.F * g.d_m * g.g_in) / (4 * fabs(dot(g.f.n, in)));
+        return;
+    }
+    double h_dot_out = dot(g.h, out);
+    double sd = g.h_dot_in + g.eta * h_dot_out;
+    D3 csq = mk(sqrt(bc.x), sqrt(bc.y), sqrt(bc.z));
+    f = csq * ((1 - g.F) * g.d_m * g_m * fabs(h_dot_out * g.h_dot_in)) / (fabs(dot(g.f.n, in)) * sd * sd);
+    pdf = ((1 - g.F) * g.d_m * g.g_in * fabs(h_dot_out * g.h_dot_in)) / (fabs(dot(g.f.n, in)) * sd * sd);
+}
 GD bool dg_sample(const Ctx &c, const GdptTexture &rough, double bsdf_eta, D3 in, D2 ruv, double rw, BsdfSample &s) {
     double eta = dot(c.v.gn, in) > 0 ? bsdf_eta : 1 / bsdf_eta;
     Frame f = oriented_frame_2s(c.v, in);
@@ -360,6 +384,26 @@ GD double db_pdf(const Ctx &c, const GdptMaterial &m, D3 in, D3 out) {
     double net = wd + wm + wc + wg;
     return (wd / net) * cos_pdf(c, in, out) + (wm / net) * dm_pdf(c, m.tex[5], m.tex[7], in, out) +
            (wc / net) * cc_pdf(c, m.tex[11], in, out) + (wg / net) * dg_pdf(c, m.tex[5], m.tex[7], p.eta, in, out);
+}
+// db_eval and db_pdf in one pass: the parameter block and the glass lobe's terms are formed once (the remaining lobes are
+// called as before: their eval and pdf differ in the roughness clamp or the cosine they divide by).
+GD void db_eval_pdf(const Ctx &c, const GdptMaterial &m, D3 in, D3 out, D3 &f, double &pdf) {
+    bool inside = dot(c.v.gn, in) <= 0;
+    DisneyParams p = disney_params(c, m, in);
+    D3 glass; double glass_pdf;
+    dg_eval_pdf(c, m.tex[0], m.tex[5], m.tex[7], p.eta, in, out, glass, glass_pdf);   // eta flipped twice (disney_bsdf.inl:29,38)
+    double wg = (1 - p.metallic) * p.spec_trans;
+    if (inside) { f = wg * glass; pdf = glass_pdf; return; }
+    double wd = (1 - p.spec_trans) * (1 - p.metallic), wm = (1 - p.spec_trans * (1 - p.metallic));
+    double wc = 0.25 * p.clearcoat, ws = (1 - p.metallic) * p.sheen;
+    D3 fd = dd_eval(c, m.tex[0], m.tex[5], m.tex[3], in, out);
+    D3 fm = dm_eval(c, p.c_0, m.tex[5], m.tex[7], in, out);
+    D3 fs = sh_eval(c, m.tex[0], m.tex[9], in, out);
+    D3 fc = cc_eval(c, m.tex[11], in, out);
+    f = wd * fd + wm * fm + wc * fc + wg * glass + ws * fs;
+    double net = wd + wm + wc + wg;
+    pdf = (wd / net) * cos_pdf(c, in, out) + (wm / net) * dm_pdf(c, m.tex[5], m.tex[7], in, out) +
+          (wc / net) * cc_pdf(c, m.tex[11], in, out) + (wg / net) * glass_pdf;
 }
 GD bool db_sample(const Ctx &c, const GdptMaterial &m, D3 in, D2 ruv, double rw, BsdfSample &s) {
     double r = ruv.x;   // fixed thresholds; the number is reused unrescaled (disney_bsdf.inl:173-191)
@@ -527,6 +571,14 @@ GD double bsdf_pdf(const DevSceneView &sv, const GdptMaterial &m, D3 in, D3 out,
         case GDPT_MAT_DISNEY_BSDF: if (TWOSIDED && mat_on<MASK, GDPT_MAT_DISNEY_BSDF>()) return db_pdf(c, m, in, out); else return 0;
         default: return 0;
     }
+}
+// eval and pdf of one direction pair (what every bounce needs): the two heavy two-sided lobes share their terms
+template <bool ROUGH = true, bool TWOSIDED = true, unsigned MASK = kAllMaterials>
+GD void bsdf_eval_pdf(const DevSceneView &sv, const GdptMaterial &m, D3 in, D3 out, const Vertex &v, D3 &f, double &pdf) {
+    if (TWOSIDED && mat_on<MASK, GDPT_MAT_DISNEY_GLASS>() && m.type == GDPT_MAT_DISNEY_GLASS) { Ctx c{sv, v}; dg_eval_pdf(c, m.tex[0], m.tex[1], m.tex[2], m.eta, in, out, f, pdf); return; }
+    if (TWOSIDED && mat_on<MASK, GDPT_MAT_DISNEY_BSDF>() && m.type == GDPT_MAT_DISNEY_BSDF) { Ctx c{sv, v}; db_eval_pdf(c, m, in, out, f, pdf); return; }
+    f = bsdf_eval<ROUGH, TWOSIDED, MASK & ~((1u << GDPT_MAT_DISNEY_GLASS) | (1u << GDPT_MAT_DISNEY_BSDF))>(sv, m, in, out, v);
+    pdf = bsdf_pdf<ROUGH, TWOSIDED, MASK & ~((1u << GDPT_MAT_DISNEY_GLASS) | (1u << GDPT_MAT_DISNEY_BSDF))>(sv, m, in, out, v);
 }
 template <bool ROUGH = true, bool TWOSIDED = true, unsigned MASK = kAllMaterials>
 GD bool bsdf_sample(const DevSceneView &sv, const GdptMaterial &m, D3 in, const Vertex &v, D2 ruv, double rw, BsdfSample &s) {

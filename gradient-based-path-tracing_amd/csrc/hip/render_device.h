@@ -553,8 +553,7 @@ GD void mat_eval_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v
         return;
     }
     const GdptMaterial &m = tx.materials[v.material_id];
-    f = bsdf_eval<ROUGH, TWOSIDED, MASK>(sv, m, in, out, v);
-    pdf = bsdf_pdf<ROUGH, TWOSIDED, MASK>(sv, m, in, out, v);
+    bsdf_eval_pdf<ROUGH, TWOSIDED, MASK>(sv, m, in, out, v, f, pdf);
 }
 template <bool LAMBERT>
 GD double mat_pdf(const DevSceneView &sv, const TraceCtx &tx, const Vertex &v, D3 in, D3 out) {
