@@ -335,6 +335,7 @@ def run_rank(args):
         pipelined = {"frames_in_flight": 2, "steps": args.steps, "ms_per_step": el2 / args.steps * 1e3,
                      "value": samples_all / (el2 / args.steps) / 1e6, "unit": "Msamples/s", "outputs_equal_sequential": same,
                      "note": "consecutive frames alternate between two HIP streams and two scene handles; not the headline value"}
+        G.poisson_forget_stream(side.cuda_stream)      # the solver keeps scratch per (device, stream): dropped with the stream
         del pa, pb, scene2
 
     # ---- strong scaling: the north-star target, 256 spp in total split over the bands

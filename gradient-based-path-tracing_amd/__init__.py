@@ -72,6 +72,7 @@ def lib():
         L.gdpt_band_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.gdpt_band_rows_weighted.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.gdpt_tile_row_costs.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.c_int]
+        L.gdpt_poisson_forget_stream.argtypes = [vp]
         L.gdpt_multi_create.argtypes = [C.POINTER(defs.GdptSceneDesc), C.POINTER(defs.GdptMultiConfig), C.POINTER(vp)]
         L.gdpt_multi_free.argtypes = [vp]
         L.gdpt_multi_free.restype = None
@@ -296,6 +297,12 @@ class MultiScene:
             self.close()
         except Exception:
             pass
+
+
+def poisson_forget_stream(stream):
+    """Drops the solver scratch kept for `stream` on the current device (gdpt_poisson_forget_stream): call before destroying a
+    stream the solver has run on."""
+    _check(lib().gdpt_poisson_forget_stream(C.c_void_p(int(stream) if stream else 0)))
 
 
 def poisson_solve_device(width, height, c_ptr, gx_ptr, gy_ptr, out_ptr, alpha=0.04, solver=defs.SOLVER_DEFAULT, tol=0.0,
