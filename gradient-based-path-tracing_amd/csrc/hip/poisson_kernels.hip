@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void dct_finalize_kernel(Geo g, const doubl
 // the DC override F^[0,0] = sum(w u) (src/render.cpp:229-239: the block holding element (0,0) reduces the per-block partials
 // of dct_rhs_kernel itself); 2 the final  out[(y*W+x)*3+ch] = f / (4 (W-1)(H-1))  (:245-247), planar -> interleaved.
 // (History, whole 512x512x3 solve on MI355X: unfolded 64x64 tiles with 4 waves 132 us, rocBLAS dgemm_strided_batched 103 us.)
-constexpr int kGemmBM = 64, kGemmBN = 64, kGemmLdB = 80, kGemmThreads = 512;
+constexpr int kGemmBN = 64, kGemmLdB = 80, kGemmThreads = 512;
 struct GemmEpi {
     double alpha; const double *lap_x, *lap_y;      // EPI 1
     const double *dc_partials; int dc_nb;            // EPI 1: [3][dc_nb] block partials of sum(w u)
@@ -308,13 +308,15 @@ struct GemmEpi {
 // to one XCD (MI355X_MICROARCH.md: workgroup dispatch; for speed only — nothing depends on it): the panel is fetched into
 // that XCD's L2 once and the other seven members hit there; the parity tables (1 MB at 512) end up in every L2.
 // Grid = 8 x ceil(groups / 8) x members blocks, 1-D; ids whose group does not exist return at once.
-template <int FORM, int EPI, int BK>
+template <int FORM, int EPI, int BK, int BM>
 __global__ __launch_bounds__(kGemmThreads, BK == 32 ? 2 : 4) void dct_fold_gemm_f64(int M, int N, int K, int tiles_m, int tiles_n, const double *X, int ldx, long long strideX,
                                                                      const double *E0, const double *E1, int ldE,
                                                                      double *C, int ldc, long long strideC, GemmEpi e) {
     typedef double d4 __attribute__((ext_vector_type(4)));
     typedef double d2 __attribute__((ext_vector_type(2)));
-    constexpr int kGemmBK = BK, kGemmLdA = BK + 1, H = BK / 16;      // H staging passes per step and thread; odd row stride, see below
+    static_assert((BM == 64 || BM == 32) && (BK == 16 || BK == 32), "tile shapes");
+    // HB / HA staging passes per step and thread for the B / A tile; odd A row stride, see above; NT MFMA tiles per wave
+    constexpr int kGemmBM = BM, kGemmBK = BK, kGemmLdA = BK + 1, HB = BK / 16, HA = BM * BK / 1024, NT = BM / 32;
     __shared__ __attribute__((aligned(16))) double sA[2][kGemmBM * kGemmLdA];
     __shared__ __attribute__((aligned(16))) double sB[2][kGemmBK * kGemmLdB];
     __shared__ double red[kBlock / 64];
@@ -341,29 +343,45 @@ __global__ __launch_bounds__(kGemmThreads, BK == 32 ? 2 : 4) void dct_fold_gemm_
     const int Mt = FORM == 0 ? M : Qn, Nt = FORM == 0 ? Qn : N;     // extent of this block's (parity-compact) output index space
     const int m0 = tile_m * kGemmBM, n0 = tile_n * kGemmBN;
     if (m0 >= Mt || n0 >= Nt) return;                    // (block-uniform: the odd parity has one output less)
-    const int wm = (wave >> 1) * 16, wn = (wave & 1) * 32;
-    // staging roles, two passes per step: A tile 64 x 32 -> thread (row tid >> 3, k = 2 (tid & 7) + 16 pass, 2 consecutive k);
-    // B tile 32 x 64 -> thread (k = (tid >> 5) + 16 pass, 2 consecutive n)
-    const int am = tid >> 3, ak = (tid & 7) * 2;
+    // a wave owns 16 rows x (16 NT) columns: 4 x 2 waves on a 64-row tile, 2 x 4 on a 32-row tile
+    const int wm = (BM == 64 ? (wave >> 1) : (wave >> 2)) * 16, wn = (BM == 64 ? (wave & 1) * 32 : (wave & 3) * 16);
+    // staging roles: A tile BM x BK -> thread (row tid / (BK/2) + (1024/BK) pass, 2 consecutive k at 2 (tid % (BK/2)));
+    // B tile BK x 64 -> thread (k = (tid >> 5) + 16 pass, 2 consecutive n)
+    const int am = tid / (BK / 2), ak = (tid % (BK / 2)) * 2;
     const int bk = tid >> 5, bn = (tid & 31) * 2;
+    constexpr int kRowsPerPass = 1024 / BK;
     const double sgn = p ? -1.0 : 1.0;
     // vector loads when every 16-byte pair is aligned and the tile lies inside the matrices (block-uniform)
     const bool fast = ((ldx | ldE | K) & 1) == 0 && m0 + kGemmBM <= Mt && n0 + kGemmBN <= Nt &&
                       ((reinterpret_cast<unsigned long long>(X) | reinterpret_cast<unsigned long long>(E)) & 15ull) == 0;
     auto fold = [&](double a, double b, int x) { return (x == mid) ? (p ? 0.0 : a) : a + sgn * b; };
-    struct Group { d2 a[H], b[H]; };                     // one K step of this thread: H (A, B) pairs
+    struct Group { d2 a[HA], b[HB]; };                   // one K step of this thread
     auto fetch = [&](int k0, Group &g) {
+        const bool vec = fast && k0 + kGemmBK <= Kf;      // (K even here: no middle sample)
 #pragma unroll
-        for (int h = 0; h < H; h++) {
-            const int ka0 = k0 + ak + 16 * h, kb = k0 + bk + 16 * h;
-            if (fast && k0 + kGemmBK <= Kf) {             // (K even here: no middle sample)
+        for (int h = 0; h < HA; h++) {                    // A tile
+            const int gm = m0 + am + kRowsPerPass * h, ka0 = k0 + ak;
+            if (vec) {
                 if (FORM == 0) {
-                    const double *row = X + (long long)(m0 + am) * ldx;
+                    const double *row = X + (long long)gm * ldx;
                     const d2 u = *reinterpret_cast<const d2 *>(row + ka0), v = *reinterpret_cast<const d2 *>(row + K - 2 - ka0);   // v = (X[K-2-x], X[K-1-x])
                     g.a[h] = d2{u.x + sgn * v.y, u.y + sgn * v.x};
-                    g.b[h] = *reinterpret_cast<const d2 *>(E + (long long)kb * ldE + n0 + bn);
-                } else {
-                    g.a[h] = *reinterpret_cast<const d2 *>(E + (long long)(m0 + am) * ldE + ka0);
+                } else g.a[h] = *reinterpret_cast<const d2 *>(E + (long long)gm * ldE + ka0);
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int ka = ka0 + j;
+                if (FORM == 0) g.a[h][j] = (gm < Mt && ka < Kf) ? fold(X[(long long)gm * ldx + ka], X[(long long)gm * ldx + (K - 1 - ka)], ka) : 0.0;
+                else g.a[h][j] = (gm < Mt && ka < Kf) ? E[(long long)gm * ldE + ka] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < HB; h++) {                    // B tile
+            const int kb = k0 + bk + 16 * h;
+            if (vec) {
+                if (FORM == 0) g.b[h] = *reinterpret_cast<const d2 *>(E + (long long)kb * ldE + n0 + bn);
+                else {
                     const d2 u = *reinterpret_cast<const d2 *>(X + (long long)kb * ldx + n0 + bn), v = *reinterpret_cast<const d2 *>(X + (long long)(K - 1 - kb) * ldx + n0 + bn);
                     g.b[h] = d2{u.x + sgn * v.x, u.y + sgn * v.y};
                 }
@@ -371,41 +389,39 @@ __global__ __launch_bounds__(kGemmThreads, BK == 32 ? 2 : 4) void dct_fold_gemm_
             }
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const int gm = m0 + am, ka = ka0 + j, gn = n0 + bn + j;
-                if (FORM == 0) {
-                    g.a[h][j] = (gm < Mt && ka < Kf) ? fold(X[(long long)gm * ldx + ka], X[(long long)gm * ldx + (K - 1 - ka)], ka) : 0.0;
-                    g.b[h][j] = (kb < Kf && gn < Nt) ? E[(long long)kb * ldE + gn] : 0.0;
-                } else {
-                    g.a[h][j] = (gm < Mt && ka < Kf) ? E[(long long)gm * ldE + ka] : 0.0;
-                    g.b[h][j] = (kb < Kf && gn < Nt) ? fold(X[(long long)kb * ldx + gn], X[(long long)(K - 1 - kb) * ldx + gn], kb) : 0.0;
-                }
+                const int gn = n0 + bn + j;
+                if (FORM == 0) g.b[h][j] = (kb < Kf && gn < Nt) ? E[(long long)kb * ldE + gn] : 0.0;
+                else g.b[h][j] = (kb < Kf && gn < Nt) ? fold(X[(long long)kb * ldx + gn], X[(long long)(K - 1 - kb) * ldx + gn], kb) : 0.0;
             }
         }
     };
     auto stage = [&](int buf, const Group &g) {
 #pragma unroll
-        for (int h = 0; h < H; h++) {
-            sA[buf][am * kGemmLdA + ak + 16 * h] = g.a[h].x; sA[buf][am * kGemmLdA + ak + 16 * h + 1] = g.a[h].y;      // (rows are only 8-byte aligned)
-            *reinterpret_cast<d2 *>(&sB[buf][(bk + 16 * h) * kGemmLdB + bn]) = g.b[h];
+        for (int h = 0; h < HA; h++) {
+            double *q = &sA[buf][(am + kRowsPerPass * h) * kGemmLdA + ak];      // (rows are only 8-byte aligned)
+            q[0] = g.a[h].x; q[1] = g.a[h].y;
         }
+#pragma unroll
+        for (int h = 0; h < HB; h++) *reinterpret_cast<d2 *>(&sB[buf][(bk + 16 * h) * kGemmLdB + bn]) = g.b[h];
     };
-    d4 acc[2];
-    acc[0] = d4{0.0, 0.0, 0.0, 0.0}; acc[1] = d4{0.0, 0.0, 0.0, 0.0};
+    d4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
     const int steps = (Kf + kGemmBK - 1) / kGemmBK;
     auto compute = [&](int buf) {
         const double *pa = sA[buf] + (wm + (lane & 15)) * kGemmLdA + (lane >> 4);
         const double *pb = sB[buf] + (lane >> 4) * kGemmLdB + wn + (lane & 15);
-        double a[kGemmBK / 4], b0[kGemmBK / 4], b1[kGemmBK / 4];
+        double a[kGemmBK / 4], bb[NT][kGemmBK / 4];
 #pragma unroll
         for (int ks = 0; ks < kGemmBK / 4; ks++) {                 // all operand reads of the step first: one LDS latency, not eight
             a[ks] = pa[ks * 4];
-            b0[ks] = pb[ks * 4 * kGemmLdB]; b1[ks] = pb[ks * 4 * kGemmLdB + 16];
+#pragma unroll
+            for (int j = 0; j < NT; j++) bb[j][ks] = pb[ks * 4 * kGemmLdB + 16 * j];
         }
 #pragma unroll
-        for (int ks = 0; ks < kGemmBK / 4; ks++) {
-            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b0[ks], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b1[ks], acc[1], 0, 0, 0);
-        }
+        for (int ks = 0; ks < kGemmBK / 4; ks++)
+#pragma unroll
+            for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], bb[j][ks], acc[j], 0, 0, 0);
     };
     Group g0, g1;
     if (BK == 32) {
@@ -450,7 +466,7 @@ __global__ __launch_bounds__(kGemmThreads, BK == 32 ? 2 : 4) void dct_fold_gemm_
         for (int k = 1; k < kBlock / 64; k++) dc += red[k];
     }
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < NT; j++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int tr = m0 + wm + (lane >> 4) + 4 * r, tc = n0 + wn + 16 * j + (lane & 15);       // parity-compact indices
@@ -686,28 +702,31 @@ PoissonResult poisson_dct(int dev, DctWorkspace &ws, int w, int h, const double 
         e.denom = 4.0 * (double)(w - 1) * (double)(h - 1); e.out = d_out; e.out_w = w;
         const int qw = (w + 1) / 2, qh = (h + 1) / 2;           // outputs of the even parity along the folded dimension
         const dim3 block(gp::kGemmThreads);
-        // tile counts of the parity-compact index spaces (even parity: the larger one), 1-D XCD-aware grids (dct_fold_gemm_f64)
-        const int tm_rows = (h + gp::kGemmBM - 1) / gp::kGemmBM, tn_rows = (qw + gp::kGemmBN - 1) / gp::kGemmBN;     // row pass: M = h, N' = ceil(w/2)
-        const int tm_cols = (qh + gp::kGemmBM - 1) / gp::kGemmBM, tn_cols = (w + gp::kGemmBN - 1) / gp::kGemmBN;     // column pass: M' = ceil(h/2), N = w
-        const dim3 grid_rows((unsigned)(8 * ((tm_rows * 3 + 7) / 8) * (tn_rows * 2)));
-        const dim3 grid_cols((unsigned)(8 * ((tn_cols * 3 + 7) / 8) * (tm_cols * 2)));
         const long long pl = (long long)plane;
         int num_cus = 256;
         { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) num_cus = prop.multiProcessorCount; }
-        // few blocks per CU: the deep-prefetch shape; many: the small-footprint shape (dct_fold_gemm_f64); test knob dct_bk forces one
-        int bk = ((long long)tm_rows * tn_rows * 6 <= 2LL * num_cus) ? 32 : 16;
-        { const int forced = gdpt::debug_knob_int("dct_bk", 0); if (forced == 16 || forced == 32) bk = forced; }
-        if (bk == 32) {
-            hipLaunchKernelGGL((gp::dct_fold_gemm_f64<0, 0, 32>), grid_rows, block, 0, stream, h, w, w, tm_rows, tn_rows, (const double *)A, w, pl, Ew[0], Ew[1], ld_ew, B, w, pl, e);      // B = A * Cw
-            hipLaunchKernelGGL((gp::dct_fold_gemm_f64<1, 1, 32>), grid_cols, block, 0, stream, h, w, h, tm_cols, tn_cols, (const double *)B, w, pl, EhT[0], EhT[1], ld_eht, A, w, pl, e);   // A = Ch^T * B, / (alpha - lambda), DC
-            hipLaunchKernelGGL((gp::dct_fold_gemm_f64<0, 0, 32>), grid_rows, block, 0, stream, h, w, w, tm_rows, tn_rows, (const double *)A, w, pl, Ew[0], Ew[1], ld_ew, B, w, pl, e);      // B = A * Cw
-            hipLaunchKernelGGL((gp::dct_fold_gemm_f64<1, 2, 32>), grid_cols, block, 0, stream, h, w, h, tm_cols, tn_cols, (const double *)B, w, pl, EhT[0], EhT[1], ld_eht, A, w, pl, e);   // out = Ch^T * B / denom
-        } else {
-            hipLaunchKernelGGL((gp::dct_fold_gemm_f64<0, 0, 16>), grid_rows, block, 0, stream, h, w, w, tm_rows, tn_rows, (const double *)A, w, pl, Ew[0], Ew[1], ld_ew, B, w, pl, e);
-            hipLaunchKernelGGL((gp::dct_fold_gemm_f64<1, 1, 16>), grid_cols, block, 0, stream, h, w, h, tm_cols, tn_cols, (const double *)B, w, pl, EhT[0], EhT[1], ld_eht, A, w, pl, e);
-            hipLaunchKernelGGL((gp::dct_fold_gemm_f64<0, 0, 16>), grid_rows, block, 0, stream, h, w, w, tm_rows, tn_rows, (const double *)A, w, pl, Ew[0], Ew[1], ld_ew, B, w, pl, e);
-            hipLaunchKernelGGL((gp::dct_fold_gemm_f64<1, 2, 16>), grid_cols, block, 0, stream, h, w, h, tm_cols, tn_cols, (const double *)B, w, pl, EhT[0], EhT[1], ld_eht, A, w, pl, e);
-        }
+        // The shape follows the grid (dct_fold_gemm_f64): with 64-row tiles, at most one block per CU -> 32-row tiles (twice the
+        // blocks, two of them resident per CU) with deep prefetch; at most two per CU -> 64 rows, deep prefetch; more -> 64 rows, the
+        // small-footprint shape. Test knobs dct_bk / dct_bm force a shape.
+        const long long blocks64 = (long long)((h + 63) / 64) * ((qw + gp::kGemmBN - 1) / gp::kGemmBN) * 6;
+        int bm = blocks64 <= num_cus ? 32 : 64, bk = blocks64 <= 2LL * num_cus ? 32 : 16;
+        { const int f = gdpt::debug_knob_int("dct_bk", 0); if (f == 16 || f == 32) bk = f; }
+        { const int f = gdpt::debug_knob_int("dct_bm", 0); if (f == 32 || f == 64) bm = f; }
+        if (bm == 32) bk = 32;                                   // (the 32-row tile exists in the deep-prefetch shape only)
+        // tile counts of the parity-compact index spaces (even parity: the larger one), 1-D XCD-aware grids
+        const int tm_rows = (h + bm - 1) / bm, tn_rows = (qw + gp::kGemmBN - 1) / gp::kGemmBN;     // row pass: M = h, N' = ceil(w/2)
+        const int tm_cols = (qh + bm - 1) / bm, tn_cols = (w + gp::kGemmBN - 1) / gp::kGemmBN;     // column pass: M' = ceil(h/2), N = w
+        const dim3 grid_rows((unsigned)(8 * ((tm_rows * 3 + 7) / 8) * (tn_rows * 2)));
+        const dim3 grid_cols((unsigned)(8 * ((tn_cols * 3 + 7) / 8) * (tm_cols * 2)));
+#define GDPT_DCT_CHAIN(BK_, BM_)                                                                                                                              \
+        hipLaunchKernelGGL((gp::dct_fold_gemm_f64<0, 0, BK_, BM_>), grid_rows, block, 0, stream, h, w, w, tm_rows, tn_rows, (const double *)A, w, pl, Ew[0], Ew[1], ld_ew, B, w, pl, e);      /* B = A * Cw */ \
+        hipLaunchKernelGGL((gp::dct_fold_gemm_f64<1, 1, BK_, BM_>), grid_cols, block, 0, stream, h, w, h, tm_cols, tn_cols, (const double *)B, w, pl, EhT[0], EhT[1], ld_eht, A, w, pl, e);   /* A = Ch^T * B, / (alpha - lambda), DC */ \
+        hipLaunchKernelGGL((gp::dct_fold_gemm_f64<0, 0, BK_, BM_>), grid_rows, block, 0, stream, h, w, w, tm_rows, tn_rows, (const double *)A, w, pl, Ew[0], Ew[1], ld_ew, B, w, pl, e);      /* B = A * Cw */ \
+        hipLaunchKernelGGL((gp::dct_fold_gemm_f64<1, 2, BK_, BM_>), grid_cols, block, 0, stream, h, w, h, tm_cols, tn_cols, (const double *)B, w, pl, EhT[0], EhT[1], ld_eht, A, w, pl, e);   /* out = Ch^T * B / denom */
+        if (bm == 32) { GDPT_DCT_CHAIN(32, 32) }
+        else if (bk == 32) { GDPT_DCT_CHAIN(32, 64) }
+        else { GDPT_DCT_CHAIN(16, 64) }
+#undef GDPT_DCT_CHAIN
     }
     ck(hipGetLastError(), "dct kernel launch");
     float ms = 0;

@@ -27,7 +27,7 @@
  *   wf_sort              (0/1/2) wavefront pipeline: ray queue in slot order / sorted by (octant, origin cell) / by (origin cell, octant)
  *   multi_fail_band / multi_fail_stage (int)  gdpt_multi_*: band `multi_fail_band` throws in stage 1 (render), 2 (halo +
  *                               assembly), 3 (all-gather) or 4 (solve): the other bands must stand down, not hang
- *   dct_bk (16 / 32)            GDPT_SOLVER_DCT_MFMA: force one of the two shapes of the folded GEMM (default: by grid size)
+ *   dct_bk (16 / 32), dct_bm (32 / 64)   GDPT_SOLVER_DCT_MFMA: force a shape of the folded GEMM (default: by grid size)
  *   replay_per_step (n >= 1)    two-sided lane machine: replay iterations of an offset per wave step (default 4; 1 = one per step)
  *   no_plain_kernel (0/1)       one-sided lane machine: the kernel with sphere and texture code even for a triangles-only, constant-texture scene
  *   full_material_switch (0/1)  lane machines: the kernel with the full material switch even when the scene fits a small set

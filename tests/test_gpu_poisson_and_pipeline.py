@@ -18,16 +18,21 @@ def weights(w, h):
     return wy[:, None, None] * wx[None, :, None]
 
 
-@pytest.mark.parametrize("solver", ["own_mfma", "rocblas"])
+GEMM_SHAPES = {"own_mfma": {}, "own_bm32": {"dct_bm": 32}, "own_bm64_bk32": {"dct_bm": 64, "dct_bk": 32}, "own_bm64_bk16": {"dct_bm": 64, "dct_bk": 16}}
+
+
+@pytest.mark.parametrize("solver", list(GEMM_SHAPES) + ["rocblas"])
 @pytest.mark.parametrize("w,h", [(8, 6), (64, 48), (2, 2), (3, 2), (33, 97), (257, 64), (512, 512), (320, 180), (65, 129), (1280, 720)])
 def test_poisson_dct_gemm_matches_dct_oracle(G, O, w, h, solver):
     """Default solver: the reference's algorithm itself, the DCT-I passes evaluated as fp64 GEMMs — the hand-written MFMA
     kernels with fused epilogues (GDPT_SOLVER_DCT_MFMA) and the rocBLAS form (the default). Same operator incl. the fp32-rounded
-    eigenvalue, so both agree with the oracle to GEMM rounding (ragged tiles, 2x2 and 2x-prime extents included)."""
-    which = G.SOLVER_DCT_MFMA if solver == "own_mfma" else G.SOLVER_DCT
+    eigenvalue, so both agree with the oracle to GEMM rounding (ragged tiles, 2x2 and 2x-prime extents included). The own
+    kernel has three tile shapes, picked by grid size; each is also forced at every extent."""
+    which = G.SOLVER_DCT_MFMA if solver in GEMM_SHAPES else G.SOLVER_DCT
     c, gx, gy = lcg_fields(w, h, seed=w * 1000 + h)
     ref = O.fourier_solve(c, gx, gy, 0.04)
-    out, st = G.fourierSolve(w, h, c, gx, gy, 0.04, solver=which, return_stats=True)
+    with G.debug_knobs(**GEMM_SHAPES.get(solver, {})):
+        out, st = G.fourierSolve(w, h, c, gx, gy, 0.04, solver=which, return_stats=True)
     assert st.solver == which and st.iterations == 0
     assert rel_l2(out, ref) < 1e-11
     np.testing.assert_allclose((weights(w, h) * out).sum(axis=(0, 1)), (weights(w, h) * c).sum(axis=(0, 1)), rtol=1e-11)
