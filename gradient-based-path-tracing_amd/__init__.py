@@ -68,6 +68,7 @@ def lib():
         L.gdpt_imread.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(dp)]
         L.gdpt_image_free.argtypes = [dp]
         L.gdpt_bvh_check.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int32)]
+        L.gdpt_sbvh_check.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int32)]
         L.gdpt_assemble_rows_device.argtypes = [C.c_int] * 4 + [vp] * 9
         L.gdpt_band_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.gdpt_band_rows_weighted.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -343,6 +344,31 @@ def bvh_check(bounds):
     return dict(zip(("bvh2_nodes", "bvh2_depth", "wide_nodes", "wide_arity", "wide_stack_need", "leaves", "max_leaf_prims", "bvh8_nodes"), list(st)[:8]))
 
 
+def sbvh_check(tri_verts, budget=0.3, samples_per_tri=16):
+    """Builds the BVH with spatial splits over n fp32 triangles (n x 3 x 3) and verifies it incl. coverage by point sampling;
+    host only. Returns the stats dict of gdpt_sbvh_check (include/gdpt.h)."""
+    t = np.ascontiguousarray(tri_verts, dtype=np.float32).reshape(-1, 9)
+    st = (C.c_int32 * 8)()
+    _check(lib().gdpt_sbvh_check(t.ctypes.data_as(C.POINTER(C.c_float)), t.shape[0], C.c_double(budget), int(samples_per_tri), st))
+    d = dict(zip(("bvh2_nodes", "bvh2_depth", "references", "wide_nodes", "wide_stack_need", "leaves"), list(st)[:6]))
+    d["sah_nodes"] = st[6] / 1000.0; d["sah_prims"] = st[7] / 1000.0
+    return d
+
+
+def shape_triangles(scene_desc):
+    """fp32 vertices of every triangle of a SceneDesc (T x 3 x 3), in shape order."""
+    d = scene_desc.desc
+    out = []
+    for i in range(d.num_shapes):
+        sh = d.shapes[i]
+        if sh.num_triangles <= 0:
+            continue
+        pos = np.ctypeslib.as_array(sh.positions, shape=(sh.num_vertices, 3)).astype(np.float32)
+        idx = np.ctypeslib.as_array(sh.indices, shape=(sh.num_triangles, 3))
+        out.append(pos[idx])
+    return np.concatenate(out, axis=0) if out else np.zeros((0, 3, 3), np.float32)
+
+
 def shape_triangle_bounds(scene_desc):
     """fp32 boxes of every triangle of a SceneDesc, in shape order (what gdpt_scene_upload hands its BVH builder)."""
     d = scene_desc.desc
@@ -409,7 +435,7 @@ class debug_knobs:
         """GDPT_FORCE_EAGER=1 -> force_eager=1 ... for the manual sweep scripts (tests/sweep_*.py, tune_render.py)."""
         environ = os.environ if environ is None else environ
         names = ("force_eager", "log2k", "keep_frac", "search_frac", "blocks_per_cu", "no_lds_scene", "lds_wide",
-                 "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "stamps", "wavefront", "wf_slots", "wf_sort", "multi_fail_band", "multi_fail_stage", "dct_bk", "dct_bm", "full_material_switch", "no_plain_kernel", "replay_per_step")
+                 "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "sbvh", "sbvh_alpha", "stamps", "wavefront", "wf_slots", "wf_sort", "multi_fail_band", "multi_fail_stage", "dct_bk", "dct_bm", "full_material_switch", "no_plain_kernel", "replay_per_step")
         lib().gdpt_debug_knobs_reset()
         for n in names:
             v = environ.get("GDPT_" + n.upper())

@@ -25,7 +25,7 @@ namespace {
 std::mutex g_knob_mu;
 std::map<std::string, double> g_knobs;     // test-only overrides, include/gdpt_debug.h
 const char *const kKnobNames[] = {"force_eager", "log2k", "keep_frac", "search_frac", "blocks_per_cu", "no_lds_scene", "lds_wide",
-                                  "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "stamps", "wavefront", "wf_slots", "wf_sort", "multi_fail_band", "multi_fail_stage", "dct_bk", "dct_bm", "full_material_switch", "no_plain_kernel", "replay_per_step"};
+                                  "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "sbvh", "sbvh_alpha", "stamps", "wavefront", "wf_slots", "wf_sort", "multi_fail_band", "multi_fail_stage", "dct_bk", "dct_bm", "full_material_switch", "no_plain_kernel", "replay_per_step"};
 double g_stamps[16] = {0};
 } // namespace
 void debug_store_stamps(const unsigned long long *v, int n) {
@@ -107,6 +107,111 @@ int gdpt_imread(const char *filename, int channels, int *width, int *height, dou
 }
 
 void gdpt_image_free(double *texels) { std::free(texels); }
+
+int gdpt_sbvh_check(const float *tri_verts9, int n, double budget, int samples_per_tri, int32_t stats[8]) {
+    return gdpt::guarded([&]() {
+        if (!tri_verts9 || n < 0 || !stats || samples_per_tri < 0) throw std::runtime_error("gdpt_sbvh_check: bad argument");
+        std::memset(stats, 0, 8 * sizeof(int32_t));
+        std::vector<float> tv(tri_verts9, tri_verts9 + 9 * (size_t)n);
+        std::vector<gdpt::PrimBounds> b((size_t)n);
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++) {
+                b[i].bmin[k] = std::min(tv[9 * i + k], std::min(tv[9 * i + 3 + k], tv[9 * i + 6 + k]));
+                b[i].bmax[k] = std::max(tv[9 * i + k], std::max(tv[9 * i + 3 + k], tv[9 * i + 6 + k]));
+            }
+        std::vector<uint32_t> ref_prim;
+        gdpt::BvhBuildResult r = gdpt::build_sbvh(b, tv, budget, &ref_prim);
+        gdpt::WideBvh wide = gdpt::collapse_for_traversal(r.nodes, false);
+        stats[0] = (int32_t)r.nodes.size(); stats[1] = r.depth; stats[2] = (int32_t)ref_prim.size();
+        stats[3] = (int32_t)wide.nodes.size(); stats[4] = wide.stack_need;
+        if (n == 0) return;
+        if (r.depth > GDPT_BVH_MAX_DEPTH || wide.stack_need > GDPT_BVH_MAX_DEPTH) throw std::runtime_error("gdpt_sbvh_check: depth or stack bound exceeded");
+        if (r.order.size() != ref_prim.size() || ref_prim.size() < (size_t)n || (double)ref_prim.size() > (1.0 + budget) * (double)n + 1.0)
+            throw std::runtime_error("gdpt_sbvh_check: reference count outside [n, (1 + budget) n]");
+        std::vector<int> refs_of((size_t)n, 0);
+        for (uint32_t o : r.order) { if (o >= ref_prim.size() || ref_prim[o] >= (uint32_t)n) throw std::runtime_error("gdpt_sbvh_check: bad reference"); refs_of[ref_prim[o]]++; }
+        for (int i = 0; i < n; i++) if (refs_of[i] < 1) throw std::runtime_error("gdpt_sbvh_check: a triangle is not referenced");
+        // structure: every leaf slot used once, children's stored boxes nest (a child's box lies inside the box its parent stores for it)
+        int leaves = 0;
+        {
+            std::vector<char> used(r.order.size(), 0);
+            struct It { int32_t node; float lo[3], hi[3]; bool root; };
+            std::vector<It> st; st.push_back({0, {0, 0, 0}, {0, 0, 0}, true});
+            while (!st.empty()) {
+                const It it = st.back(); st.pop_back();
+                const DevBvhNode &nd = r.nodes[(size_t)it.node];
+                const int32_t ch[2] = {nd.left, nd.right};
+                const float *lo[2] = {nd.lmin, nd.rmin}, *hi[2] = {nd.lmax, nd.rmax};
+                for (int c = 0; c < 2; c++) {
+                    if (ch[c] == GDPT_CHILD_EMPTY) continue;
+                    if (!it.root) for (int k = 0; k < 3; k++) if (!(it.lo[k] <= lo[c][k] && hi[c][k] <= it.hi[k])) throw std::runtime_error("gdpt_sbvh_check: a child box sticks out of its parent's");
+                    if (ch[c] >= 0) { It nx; nx.node = ch[c]; nx.root = false; for (int k = 0; k < 3; k++) { nx.lo[k] = lo[c][k]; nx.hi[k] = hi[c][k]; } st.push_back(nx); }
+                    else {
+                        const unsigned packed = ~(unsigned)ch[c], first = packed >> 2, cnt = (packed & 3u) + 1u;
+                        if (first + cnt > r.order.size()) throw std::runtime_error("gdpt_sbvh_check: leaf range out of bounds");
+                        for (unsigned i = 0; i < cnt; i++) { if (used[first + i]) throw std::runtime_error("gdpt_sbvh_check: leaf slot used twice"); used[first + i] = 1; }
+                        leaves++;
+                    }
+                }
+            }
+            for (char u : used) if (!u) throw std::runtime_error("gdpt_sbvh_check: leaf slot not reachable");
+        }
+        stats[5] = leaves;
+        {   // surface-area cost of the collapsed tree: expected child boxes entered / triangles tested by a random line through the root box
+            auto ha = [](const float *lo, const float *hi) { const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2]; return dx * dy + dy * dz + dz * dx; };
+            float rlo[3] = {INFINITY, INFINITY, INFINITY}, rhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (int c = 0; c < 4; c++) if (wide.nodes[0].child[c] != GDPT_CHILD_EMPTY) for (int k = 0; k < 3; k++) { rlo[k] = std::min(rlo[k], wide.nodes[0].lo[k][c]); rhi[k] = std::max(rhi[k], wide.nodes[0].hi[k][c]); }
+            const double ra = ha(rlo, rhi);
+            double cn = 1.0, cp = 0.0;
+            for (const DevBvh4Node &nd : wide.nodes)
+                for (int c = 0; c < 4; c++) {
+                    if (nd.child[c] == GDPT_CHILD_EMPTY) continue;
+                    const float lo[3] = {nd.lo[0][c], nd.lo[1][c], nd.lo[2][c]}, hi[3] = {nd.hi[0][c], nd.hi[1][c], nd.hi[2][c]};
+                    const double a = ra > 0 ? ha(lo, hi) / ra : 0.0;
+                    if (nd.child[c] >= 0) cn += a; else cp += a * (double)(((~(unsigned)nd.child[c]) & 3u) + 1u);
+                }
+            stats[6] = (int32_t)std::lround(std::min(cn, 2e6) * 1000.0); stats[7] = (int32_t)std::lround(std::min(cp, 2e6) * 1000.0);
+        }
+        // coverage by point sampling, in the collapsed tree the kernels walk (same boxes)
+        auto covered = [&](const double p[3], uint32_t prim) {
+            std::vector<int32_t> st{0};
+            while (!st.empty()) {
+                const DevBvh4Node &nd = wide.nodes[(size_t)st.back()]; st.pop_back();
+                for (int c = 0; c < 4; c++) {
+                    if (nd.child[c] == GDPT_CHILD_EMPTY) continue;
+                    bool in = true;
+                    for (int k = 0; k < 3; k++) if (!((double)nd.lo[k][c] <= p[k] && p[k] <= (double)nd.hi[k][c])) in = false;
+                    if (!in) continue;
+                    if (nd.child[c] >= 0) { st.push_back(nd.child[c]); continue; }
+                    const unsigned packed = ~(unsigned)nd.child[c], first = packed >> 2, cnt = (packed & 3u) + 1u;
+                    for (unsigned i = 0; i < cnt; i++) if (ref_prim[r.order[first + i]] == prim) return true;
+                }
+            }
+            return false;
+        };
+        for (int i = 0; i < n; i++) {
+            double v[3][3];
+            for (int a = 0; a < 3; a++) for (int k = 0; k < 3; k++) v[a][k] = tv[9 * (size_t)i + 3 * a + k];
+            for (int s = 0; s < samples_per_tri; s++) {
+                double w[3];
+                if (s < 3) { w[0] = s == 0; w[1] = s == 1; w[2] = s == 2; }
+                else if (s < 6) { w[0] = s == 3 ? 0 : 0.5; w[1] = s == 4 ? 0 : 0.5; w[2] = s == 5 ? 0 : 0.5; }
+                else if (s == 6) { w[0] = w[1] = w[2] = 1.0 / 3.0; }
+                else {      // additive-recurrence lattice folded into the triangle
+                    double a = std::fmod(0.7548776662466927 * (s - 6) + 0.31 * i, 1.0), bb = std::fmod(0.5698402909980532 * (s - 6) + 0.17 * i, 1.0);
+                    if (a + bb > 1.0) { a = 1.0 - a; bb = 1.0 - bb; }
+                    w[0] = a; w[1] = bb; w[2] = 1.0 - a - bb;
+                }
+                double p[3];
+                for (int k = 0; k < 3; k++) {       // inside the vertices' extent whatever the rounding of the weights
+                    p[k] = w[0] * v[0][k] + w[1] * v[1][k] + w[2] * v[2][k];
+                    p[k] = std::min(std::max(p[k], (double)b[i].bmin[k]), (double)b[i].bmax[k]);
+                }
+                if (!covered(p, (uint32_t)i)) throw std::runtime_error("gdpt_sbvh_check: a point of a triangle is in no leaf box that references the triangle");
+            }
+        }
+    });
+}
 
 int gdpt_bvh_check(const float *bounds6, int n, int32_t stats[8]) {
     return gdpt::guarded([&]() {

@@ -36,6 +36,7 @@ T *upload(const std::vector<T> &v) {
 } // namespace
 
 static constexpr int kWavefrontDefault = 0;       // HBM scenes: 1 = wavefront pipeline by default, 0 = lane machine
+static constexpr double kSbvhBudget = 1.0;       // extra references / primitives the spatial-split build may add (it adds ~0.1-0.35; knob sbvh overrides)
 static constexpr double kPresplitBudget = 0.0;   // extra references / primitives (GDPT_PRESPLIT overrides)
 
 namespace gdpt {
@@ -136,7 +137,10 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
         budget = gdpt::debug_knob("presplit", budget);
         gdpt::presplit_triangles(bounds, tri_verts, budget, &refs, &ref_prim);
     }
-    gdpt::BvhBuildResult bvh = gdpt::build_bvh(refs);
+    // spatial splits inside the SAH build (host/sbvh.cpp) for meshes that are walked from HBM; `sbvh` = extra references allowed
+    // per primitive (test knob; 0 = the plain object-split build)
+    const double sbvh_budget = gdpt::debug_knob("sbvh", tris.size() >= 4096 ? kSbvhBudget : 0.0);
+    gdpt::BvhBuildResult bvh = sbvh_budget > 0 ? gdpt::build_sbvh(bounds, tri_verts, sbvh_budget, &ref_prim) : gdpt::build_bvh(refs);
     {   // widen every child box: the traversal's slab test then needs no per-test padding (device_trace.h: box_hit)
         float ext = 0.f;
         for (int k = 0; k < 3; k++) if (ub[k] >= lb[k]) ext = std::max(ext, std::max(std::fabs(ub[k]), std::fabs(lb[k])));

@@ -69,9 +69,6 @@ template <bool ON> struct Stamps {
 };
 struct Accum { D3 r, dx0, dy0, dx1, dy1; };
 
-constexpr int kQueueRegions = 8;       // one per XCD
-constexpr int kQueueStride = 16;       // unsigned long longs between two heads: each in its own 128-byte line
-
 struct KernelArgs {
     int spp, log2k, tile_w, tile_h, tiles_x;
     int row_begin, row_end, max_depth;
@@ -84,9 +81,7 @@ struct KernelArgs {
     long long num_items;               // num_slots * num_chunks (< 2^32); item = chunk * num_slots + slot ("tier-major")
     double *partials;                  // [num_items][16]: 15 sums (r, dx0, dy0, dx1, dy1 as xyz) + pad, 128-B records
     int chunk_begin[gdpt::kMaxChunks + 1];
-    unsigned long long *queue_head;    // work-queue head(s) (zeroed per launch): head q at queue_head[q * kQueueStride]
-    int regions_x, regions_y;          // > 0: one queue per film region (WaveQueue), regions_x * regions_y = kQueueRegions; 0: one queue
-    int region_tw, region_th, tiles_y; // tiles per region (the last column / row of regions may hold fewer), tile rows of the band
+    unsigned long long *queue_head;    // work-queue head (zeroed per launch)
     double *img, *cx0, *cy0, *cx1, *cy1;
     gdpt::RenderCounters *counters;
 };
@@ -323,6 +318,9 @@ GD void visit_wide8(const DevBvh8Node &n, const float oi[3], const float inv[3],
 
 // A leaf holds 1..4 primitive records. All of them are fetched before the first test (indices clamped to the leaf, so
 // short leaves re-read their last record): the leaf then costs one memory latency instead of one per primitive.
+// (Tried: not fetching the slots a leaf does not fill — exec-masked loads instead of clamped indices, a third fewer requests per
+// leaf: sponza -2.7 %, the Disney scenes -6..-10 %, profiles/r03_ab_leaf_loads.txt; the mask bookkeeping costs more than the
+// re-reads of a line the lane has just fetched.)
 template <bool FLAT, bool SPHERES = true>
 GD void test_leaf(const DevSceneView &sv, const TraceCtx &tx, int cur, const float o[3], const float d[3], float tnear, float tfar,
                   Hit &best, TraceCounters &tc) {
@@ -932,78 +930,30 @@ GD bool item_to_pixel(const KernelArgs &a, int W, unsigned item, int &x, int &y,
 // that no wave sits on unstarted items while others have run dry. (Shrinking the slices from half-way through the
 // queue, as an earlier version did, made the second half of the kernel pay the round trip on almost every step:
 // 15 % of all wave cycles on cbox 512x512x16.)
-//
-// Scenes walked from HBM: one queue per XCD (KernelArgs::regions_x > 0). Each of the eight XCDs has its own 4 MB L2, and the
-// 131 k items in flight on the chip are 20 % of a 1280x720 film: with one queue every L2 sees the tree and the triangles under
-// that whole sweep front. The band's tiles are cut into 8 rectangles of region_tw x region_th tiles; a wave draws from the queue
-// of the region that carries its XCD's number (XCC_ID register: no assumption about how blocks are dealt to XCDs), chunk-major
-// inside the region, and moves on to the next region's queue when its own has run dry — every queue is drained whatever the
-// placement of the waves. A queue position is translated to the item number of the one-queue layout, so partial records,
-// reduction and results are the same bits.
-GD int xcc_id() { return (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u); }     // HW_REG_XCC_ID[3:0]
 struct WaveQueue {
     long long next = 0, end = 0, seen_head = 0;
-    int q = -1, q_tried = 0;                 // region queues: the queue the current slice came from, queues found dry
     bool exhausted = false;
-    GD void region(const KernelArgs &a, int qi, int &tx0, int &ty0, int &tw, int &th) const {
-        const int qy = qi / a.regions_x, qx = qi - qy * a.regions_x;
-        tx0 = qx * a.region_tw; ty0 = qy * a.region_th;
-        tw = min(a.region_tw, a.tiles_x - tx0); th = min(a.region_th, a.tiles_y - ty0);
-        if (tw < 0) tw = 0;
-        if (th < 0) th = 0;
-    }
     GD long long take(const KernelArgs &a, bool idle, int tid) {
         long long item = -1;
         const unsigned long long m_idle = __ballot(idle);
         if (m_idle) {
-            const bool regions = a.regions_x > 0;
             if (next >= end && !exhausted) {
-                const unsigned waves_all = gridDim.x * (unsigned)(kBlock / 64);
+                const unsigned left = (unsigned)(a.num_items - seen_head);          // num_items < 2^32
+                const unsigned waves = gridDim.x * (unsigned)(kBlock / 64);
                 const long long n_idle_now = __popcll(m_idle);
-                if (!regions) {
-                    const unsigned left = (unsigned)(a.num_items - seen_head);          // num_items < 2^32
-                    long long want = 64;
-                    if (left < waves_all * 64u) { want = (long long)(left / (waves_all * 2u)); want = want > 64 ? 64 : (want < n_idle_now ? n_idle_now : want); }
-                    unsigned long long got = 0;
-                    if ((tid & 63) == 0) got = atomicAdd(a.queue_head, (unsigned long long)want);
-                    got = __shfl(got, 0, 64);
-                    next = (long long)got;
-                    end = min((long long)got + want, a.num_items);
-                    seen_head = end;
-                    if (next >= a.num_items) { exhausted = true; end = next; }
-                } else {
-                    if (q < 0) q = xcc_id();
-                    const unsigned waves = (waves_all + kQueueRegions - 1) / kQueueRegions;
-                    for (;;) {
-                        if (q_tried >= kQueueRegions) { exhausted = true; end = next; break; }
-                        int tx0, ty0, tw, th;
-                        region(a, q, tx0, ty0, tw, th);
-                        const long long n_q = (long long)tw * th * 256 * a.num_chunks;
-                        const unsigned left = (unsigned)(n_q > seen_head ? n_q - seen_head : 0);
-                        long long want = 64;
-                        if (left < waves * 64u) { want = (long long)(left / (waves * 2u)); want = want > 64 ? 64 : (want < n_idle_now ? n_idle_now : want); }
-                        unsigned long long got = (unsigned long long)n_q;
-                        if (n_q > 0) {
-                            if ((tid & 63) == 0) got = atomicAdd(a.queue_head + q * kQueueStride, (unsigned long long)want);
-                            got = __shfl(got, 0, 64);
-                        }
-                        if ((long long)got < n_q) { next = (long long)got; end = min((long long)got + want, n_q); seen_head = end; break; }
-                        q = (q + 1 == kQueueRegions) ? 0 : q + 1; q_tried++; seen_head = 0;      // this one is dry (heads only grow): never asked again
-                    }
-                }
+                long long want = 64;
+                if (left < waves * 64u) { want = (long long)(left / (waves * 2u)); want = want > 64 ? 64 : (want < n_idle_now ? n_idle_now : want); }
+                unsigned long long got = 0;
+                if ((tid & 63) == 0) got = atomicAdd(a.queue_head, (unsigned long long)want);
+                got = __shfl(got, 0, 64);
+                next = (long long)got;
+                end = min((long long)got + want, a.num_items);
+                seen_head = end;
+                if (next >= a.num_items) { exhausted = true; end = next; }
             }
             const int avail = (int)(end - next);
             const int rank = __popcll(m_idle & ((1ull << (tid & 63)) - 1ull));
-            if (idle && rank < avail) {
-                item = next + rank;
-                if (regions) {                              // position in the region's queue -> item of the one-queue layout
-                    int tx0, ty0, tw, th;
-                    region(a, q, tx0, ty0, tw, th);
-                    const unsigned per = (unsigned)(tw * th * 256), pos = (unsigned)item;
-                    const unsigned c = pos / per, r = pos - c * per, lt = r >> 8, lty = lt / (unsigned)tw, ltx = lt - lty * (unsigned)tw;
-                    item = (long long)c * a.num_slots + (long long)(((unsigned)ty0 + lty) * (unsigned)a.tiles_x + (unsigned)tx0 + ltx) * 256 + (r & 255u);
-                }
-            }
+            if (idle && rank < avail) item = next + rank;
             const int n_idle = __popcll(m_idle);
             next += (n_idle < avail) ? n_idle : avail;
         }

@@ -38,6 +38,12 @@ struct WideBvh { std::vector<DevBvh4Node> nodes; std::vector<DevBvh8Node> nodes8
 // with_bvh8: also the quantised 8-wide form (the host check and the GDPT_HBM_BVH8 A/B build; product uploads do not need it)
 WideBvh collapse_for_traversal(const std::vector<DevBvhNode> &nodes, bool with_bvh8);
 
+// The same tree form built with spatial splits (host/sbvh.cpp): a triangle that straddles a chosen split plane is referenced from
+// both children. `tri_verts`: 9 floats per triangle for the first tri_verts.size()/9 entries of `bounds` (spheres follow, never
+// split). `budget` = extra references allowed as a fraction of the primitive count. On return ref_prim[order[i]] = primitive stored
+// at leaf slot i (order.size() = references >= primitives).
+BvhBuildResult build_sbvh(const std::vector<PrimBounds> &bounds, const std::vector<float> &tri_verts, double budget, std::vector<uint32_t> *ref_prim);
+
 } // namespace gdpt
 
 namespace gdpt {

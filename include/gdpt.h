@@ -357,6 +357,15 @@ void gdpt_image_free(double *texels);
  * nodes, [3] BVH4 node arity used (2..4), [4] traversal-stack bound of the BVH4, [5] leaves, [6] max primitives per
  * leaf, [7] BVH8 nodes. */
 int gdpt_bvh_check(const float *bounds6, int n, int32_t stats[8]);
+/* The same for the build with spatial splits (host/sbvh.cpp; what gdpt_scene_upload uses for meshes walked from HBM): over `n`
+ * fp32 triangles (tri_verts9 = n x 3 vertices x xyz) with `budget` extra references per primitive allowed. Verifies that child
+ * boxes enclose the reference boxes below them, that every triangle is referenced, the depth and stack bounds of the collapsed
+ * form, and COVERAGE: for `samples_per_tri` points on every triangle (its vertices, edge midpoints, centroid, then points from a
+ * fixed lattice), descending from the root through every child box that contains the point reaches a leaf that references the
+ * triangle — a ray that hits the triangle there cannot miss it in the tree. stats: [0] BVH2 nodes, [1] BVH2 depth, [2] references
+ * (>= n), [3] BVH4 nodes, [4] BVH4 stack bound, [5] leaves, [6] / [7] 1000 x the surface-area cost of the BVH4: inner nodes entered /
+ * triangles tested per random line through the root box. */
+int gdpt_sbvh_check(const float *tri_verts9, int n, double budget, int samples_per_tri, int32_t stats[8]);
 
 const char *gdpt_last_error(void);
 /* "gfx950" etc. of the device the library's kernels were built for, and the running device name. */

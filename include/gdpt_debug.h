@@ -21,6 +21,8 @@
  *   presplit_floor       (real) pre-split priority floor (scene upload)
  *   bvh_leaf_max         (1..4) SAH builder: primitives per leaf (scene upload)
  *   bvh_leaf_factor      (real) SAH builder: leaf cost factor (scene upload)
+ *   sbvh                 (real) SAH builder with spatial splits: extra references allowed per primitive, 0 = object splits only (scene upload)
+ *   sbvh_alpha           (real) ... spatial splits are tried where the object split's children overlap by more than this fraction of the root's area
  *   wavefront            (0/1)  scenes walked from HBM, one-sided lobes: 1 = wavefront pipeline (step + trace kernels, path
  *                               state in HBM), 0 = lane machine; the two give bit-identical images
  *   wf_slots             (int)  wavefront pipeline: at most this many path slots (forces slots to run several items)
