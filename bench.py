@@ -233,8 +233,11 @@ def run_rank(args):
         def solve(c, cx, cy, out, want_stats):
             return G.poisson_solve_device(W, H, ptr(c), ptr(cx), ptr(cy), ptr(out), alpha=args.alpha, stream=stream, want_stats=want_stats)
 
+        def assemble_solve(bufs, dst, out, want_stats):
+            return G.assemble_solve_device(W, H, [ptr(bufs[k]) for k in names], [ptr(t) for t in dst], ptr(out), alpha=args.alpha, stream=stream, want_stats=want_stats)
+
         return sharding.ShardedGradPath(dist, world, rank, H, lambda: torch.zeros((H, W, 3), dtype=torch.float64, device=dev),
-                                        render_band, assemble, solve, phase_hook=hook, bands=bands)
+                                        render_band, assemble, solve, phase_hook=hook, bands=bands, assemble_solve=assemble_solve)
 
     def fence():
         if world > 1:
@@ -500,8 +503,9 @@ def _kernel_lines(got, W, H, spp, pmc):
                       "traffic": pmc.hbm_bytes(_find(got["counters"], pattern) or {})})
     items = ((W + 15) // 16) * ((H + 15) // 16) * 256 * _num_chunks(spp, W * H)
     add("gdpt_reduce_partials", "gd::gdpt_reduce_partials", items * 128.0 + 5 * n3 * 8.0)   # 128-B record per work item in, five images out
-    add("assemble_kernel", "gp::assemble_kernel", 8 * 8.0 * n3)            # 5 reads + 3 writes per unknown
-    add("dct_rhs_kernel", "gp::dct_rhs_kernel", 4 * 8.0 * n3)              # read c, cx, cy; write h
+    add("assemble_rhs_kernel", "gp::assemble_rhs_kernel", 9 * 8.0 * n3)    # one rank: assembly + right-hand side in one pass, 5 reads + 4 writes per unknown
+    add("assemble_kernel", "gp::assemble_kernel", 8 * 8.0 * n3)            # (several ranks: 5 reads + 3 writes per unknown ...
+    add("dct_rhs_kernel", "gp::dct_rhs_kernel", 4 * 8.0 * n3)              #  ... then read c, cx, cy; write h)
     for k, t in got["times"].items():
         if "dct_fold_gemm_f64" in k:          # own kernels: two row passes (X*Cw) + two column passes (Ch^T*T) per step, all under one name
             nominal = 2.0 * 3 * (W * W * H + H * H * W) / 2          # flops of one UNFOLDED pass, mean of the two shapes

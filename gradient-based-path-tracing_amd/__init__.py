@@ -62,6 +62,8 @@ def lib():
                                             C.POINTER(defs.GdptPoissonStats)]
         L.gdpt_poisson_solve_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, C.c_int, C.c_double, C.c_int,
                                                 vp, C.POINTER(defs.GdptPoissonStats)]
+        L.gdpt_assemble_solve_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_double, vp, C.c_int, C.c_double, C.c_int,
+                                                 vp, C.POINTER(defs.GdptPoissonStats)]
         L.gdpt_gradient_path_render.argtypes = [vp, C.POINTER(defs.GdptRenderParams), C.c_double, dp, dp, dp, dp, dp, dp,
                                                 C.POINTER(defs.GdptRenderStats), C.POINTER(defs.GdptPoissonStats)]
         L.gdpt_imwrite.argtypes = [C.c_char_p, C.c_int, C.c_int, dp]
@@ -316,6 +318,17 @@ def poisson_solve_device(width, height, c_ptr, gx_ptr, gy_ptr, out_ptr, alpha=0.
     return st
 
 
+def assemble_solve_device(width, height, src_ptrs, dst_ptrs, out_ptr, alpha=0.04, solver=defs.SOLVER_DEFAULT, tol=0.0, max_iters=0,
+                          stream=None, want_stats=False):
+    """assemble_device over the whole film + poisson_solve_device on its outputs as one call (gdpt_assemble_solve_device): the
+    assembly and the solver's right-hand side are one pass over the film. `src_ptrs` = img, cx0, cy0, cx1, cy1; `dst_ptrs` = c, cx, cy."""
+    st = defs.GdptPoissonStats() if want_stats else None
+    _check(lib().gdpt_assemble_solve_device(int(width), int(height), *[C.c_void_p(int(x)) for x in src_ptrs], *[C.c_void_p(int(x)) for x in dst_ptrs],
+                                            float(alpha), C.c_void_p(int(out_ptr)), int(solver), float(tol), int(max_iters),
+                                            C.c_void_p(int(stream) if stream else 0), C.byref(st) if st is not None else None))
+    return st
+
+
 def imwrite(filename, image):
     """.pfm (fp32) / .exr (fp16) by suffix, like src/image.cpp:135-173."""
     img = np.ascontiguousarray(image, dtype=np.float64)
@@ -435,7 +448,7 @@ class debug_knobs:
         """GDPT_FORCE_EAGER=1 -> force_eager=1 ... for the manual sweep scripts (tests/sweep_*.py, tune_render.py)."""
         environ = os.environ if environ is None else environ
         names = ("force_eager", "log2k", "keep_frac", "search_frac", "blocks_per_cu", "no_lds_scene", "lds_wide",
-                 "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "sbvh", "sbvh_alpha", "stamps", "wavefront", "wf_slots", "wf_sort", "multi_fail_band", "multi_fail_stage", "dct_bk", "dct_bm", "full_material_switch", "no_plain_kernel", "replay_per_step")
+                 "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "sbvh", "sbvh_alpha", "bvh_collapse_dp", "stamps", "wavefront", "wf_slots", "wf_sort", "multi_fail_band", "multi_fail_stage", "dct_bk", "dct_bm", "full_material_switch", "no_plain_kernel", "replay_per_step")
         lib().gdpt_debug_knobs_reset()
         for n in names:
             v = environ.get("GDPT_" + n.upper())

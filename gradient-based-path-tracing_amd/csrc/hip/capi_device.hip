@@ -706,6 +706,17 @@ int gdpt_assemble_device(int width, int height, const double *d_img, const doubl
     return gdpt_assemble_rows_device(width, height, 0, 0, d_img, d_cx0, d_cy0, d_cx1, d_cy1, d_c, d_cx, d_cy, stream);
 }
 
+int gdpt_assemble_solve_device(int width, int height, const double *d_img, const double *d_cx0, const double *d_cy0, const double *d_cx1, const double *d_cy1,
+                               double *d_c, double *d_cx, double *d_cy, double dataCost, double *d_out, int solver, double tol, int max_iters,
+                               void *stream, GdptPoissonStats *stats) {
+    return gdpt::guarded([&]() {
+        if (!d_img || !d_cx0 || !d_cy0 || !d_cx1 || !d_cy1 || !d_c || !d_cx || !d_cy || !d_out) throw std::runtime_error("gdpt_assemble_solve_device: null buffer");
+        gdpt::PoissonResult r = gdpt::assemble_solve_device(width, height, d_img, d_cx0, d_cy0, d_cx1, d_cy1, d_c, d_cx, d_cy, dataCost, d_out, solver, tol, max_iters,
+                                                            (hipStream_t)stream, stats != nullptr);
+        if (stats) { stats->iterations = r.iterations; stats->solver = r.solver; stats->rel_residual = r.rel_residual; stats->solve_ms = r.solve_ms; }
+    });
+}
+
 int gdpt_poisson_forget_stream(void *stream) {
     return gdpt::guarded([&]() {
         int dev = 0;
@@ -767,8 +778,7 @@ int gdpt_gradient_path_render(GdptScene *scene, const GdptRenderParams *params, 
         p.row_begin = 0; p.row_end = 0;   // the solve is global: whole image only
         GdptRenderStats local{};
         render_device_impl(scene, &p, scene->scene_spp, b[0], b[1], b[2], b[3], b[4], nullptr, rstats ? rstats : &local);
-        gdpt::launch_assemble(w, h, 0, 0, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], nullptr);
-        gdpt::PoissonResult r = gdpt::poisson_solve_device(w, h, b[5], b[6], b[7], dataCost, b[8], GDPT_SOLVER_DEFAULT, 0.0, 0, nullptr, pstats != nullptr);
+        gdpt::PoissonResult r = gdpt::assemble_solve_device(w, h, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], dataCost, b[8], GDPT_SOLVER_DEFAULT, 0.0, 0, nullptr, pstats != nullptr);
         if (pstats) { pstats->iterations = r.iterations; pstats->solver = r.solver; pstats->rel_residual = r.rel_residual; pstats->solve_ms = r.solve_ms; }
         ck(hipMemcpy(out_image, b[8], elems * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
         double *host[5] = {img, cx0, cy0, cx1, cy1};

@@ -18,6 +18,12 @@ void launch_assemble(int w, int h, int row_begin, int row_end, const double *img
 PoissonResult poisson_solve_device(int w, int h, const double *d_c, const double *d_gx, const double *d_gy, double alpha,
                                    double *d_out, int solver, double tol, int max_iters, hipStream_t stream, bool timed);
 
+// launch_assemble over the whole film followed by poisson_solve_device on its outputs, with the first two passes over the film fused
+// for the DCT solvers (c / cx / cy are still written; same bits as the two calls).
+PoissonResult assemble_solve_device(int w, int h, const double *img, const double *cx0, const double *cy0, const double *cx1, const double *cy1,
+                                    double *d_c, double *d_cx, double *d_cy, double alpha, double *d_out, int solver, double tol, int max_iters,
+                                    hipStream_t stream, bool timed);
+
 // Drops the (device, stream) pair's scratch state; call before destroying a stream the solver has run on (nothing in flight).
 void poisson_forget_stream(int dev, hipStream_t stream);
 void poisson_release_workspace();

@@ -235,6 +235,31 @@ __global__ __launch_bounds__(kBlock) void dct_rhs_kernel(Geo g, double alpha, co
 #pragma unroll
     for (int k = 0; k < 3; k++) { double v = block_sum(s_wu[k], red); if (threadIdx.x == 0) partials[k * nb + blockIdx.x] = v; }
 }
+// assemble_kernel + dct_rhs_kernel in one pass over the film (whole images on one device): the five rendered buffers are read
+// once, c / cx / cy written once and not read back — every value by the expression the two kernels use, so the bits are theirs.
+__global__ __launch_bounds__(kBlock) void assemble_rhs_kernel(Geo g, double alpha, const double *img, const double *cx0, const double *cy0, const double *cx1,
+                                                              const double *cy1, double *c, double *cx, double *cy, double *hplanar, double *partials) {
+    __shared__ double red[kBlock / 64];
+    const int plane = g.w * g.h;
+    double s_wu[3] = {0, 0, 0};
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < g.n3; i += gridDim.x * kBlock) {
+        int y = i / g.row, col = i - y * g.row, xx = col / 3, ch = col - xx * 3;
+        const double ui = img[i];
+        const double gxi = (xx == 0) ? cx0[i] : cx0[i] + cx1[i - 3];
+        const double gyi = (y == 0) ? cy0[i] : cy0[i] + cy1[i - g.row];
+        c[i] = ui; cx[i] = gxi; cy[i] = gyi;
+        double hv = alpha * ui;
+        if (xx > 0 && xx < g.w - 1) hv -= ((cx0[i + 3] + cx1[i]) - gxi); else hv -= (-2.0 * gxi);
+        if (y > 0 && y < g.h - 1) hv -= ((cy0[i + g.row] + cy1[i]) - gyi); else hv -= (-2.0 * gyi);
+        hplanar[(size_t)ch * plane + (size_t)y * g.w + xx] = hv;
+        double wgt = weight(g, xx, y);
+#pragma unroll
+        for (int k = 0; k < 3; k++) if (ch == k) s_wu[k] += wgt * ui;
+    }
+    const int nb = gridDim.x;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { double v = block_sum(s_wu[k], red); if (threadIdx.x == 0) partials[k * nb + blockIdx.x] = v; }
+}
 // F^ = H^ / (alpha - (float)(lapY[y] + lapX[x]))  (:229-235)
 __global__ __launch_bounds__(kBlock) void dct_scale_kernel(Geo g, double alpha, const double *lap_x, const double *lap_y, double *hhat) {
     const int plane = g.w * g.h;
@@ -644,8 +669,9 @@ const double *get_lap_y(DctTables &t, int h) {   // ftLapY = -4 + 2 cos(pi y/(h-
 }
 
 // Enqueue-only unless `timed`: no event is created, recorded or waited for on the product path (stats == NULL).
+// `raw` (nullable): the five rendered buffers — then d_c / d_gx / d_gy are OUTPUTS of the fused first pass (assemble_rhs_kernel).
 PoissonResult poisson_dct(int dev, DctWorkspace &ws, int w, int h, const double *d_c, const double *d_gx, const double *d_gy, double alpha,
-                          double *d_out, hipStream_t stream, bool timed, bool library_gemm) {
+                          double *d_out, hipStream_t stream, bool timed, bool library_gemm, const double *const *raw = nullptr) {
     if (library_gemm) {
         if (!ws.handle) rb(rocblas_create_handle(&ws.handle), "rocblas_create_handle");
         rb(rocblas_set_stream(ws.handle, stream), "rocblas_set_stream");
@@ -676,7 +702,9 @@ PoissonResult poisson_dct(int dev, DctWorkspace &ws, int w, int h, const double 
         ck(hipEventRecord(ws.ev[0], stream), "hipEventRecord");
     }
     double *A = ws.buf[0], *B = ws.buf[1];
-    hipLaunchKernelGGL(gp::dct_rhs_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, alpha, d_c, d_gx, d_gy, A, ws.partials);
+    if (raw) hipLaunchKernelGGL(gp::assemble_rhs_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, alpha, raw[0], raw[1], raw[2], raw[3], raw[4],
+                                const_cast<double *>(d_c), const_cast<double *>(d_gx), const_cast<double *>(d_gy), A, ws.partials);
+    else hipLaunchKernelGGL(gp::dct_rhs_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, alpha, d_c, d_gx, d_gy, A, ws.partials);
     const double one = 1.0, zero = 0.0;
     // Row-major X (h x w) is the column-major matrix X^T (w x h, ld = w). Row transform T = X * Cw  <=>  T^T = Cw^T * X^T:
     // the row-major buffer of Cw read column-major IS Cw^T, so (N, N). Column transform Y = Ch^T * T  <=>  Y^T = T^T * Ch:
@@ -781,6 +809,26 @@ void launch_assemble(int w, int h, int row_begin, int row_end, const double *img
     int nb = std::min(gp::kMaxBlocks * 2, (n + gp::kBlock - 1) / gp::kBlock);
     hipLaunchKernelGGL(gp::assemble_kernel, dim3(nb), dim3(gp::kBlock), 0, stream, g, row_begin, row_end, img, cx0, cy0, cx1, cy1, c, cx, cy);
     ck(hipGetLastError(), "assemble kernel launch");
+}
+
+PoissonResult assemble_solve_device(int w, int h, const double *img, const double *cx0, const double *cy0, const double *cx1, const double *cy1,
+                                    double *d_c, double *d_cx, double *d_cy, double alpha, double *d_out, int solver, double tol, int max_iters,
+                                    hipStream_t stream, bool timed) {
+    if (solver == GDPT_SOLVER_CG) {      // (the CG reads c / cx / cy several times: nothing to fuse)
+        launch_assemble(w, h, 0, 0, img, cx0, cy0, cx1, cy1, d_c, d_cx, d_cy, stream);
+        return poisson_solve_device(w, h, d_c, d_cx, d_cy, alpha, d_out, solver, tol, max_iters, stream, timed);
+    }
+    if (w < 2 || h < 2) throw std::runtime_error("poisson: width and height must be >= 2 (the reference divides by (W-1)(H-1))");
+    if (!(alpha > 0)) throw std::runtime_error("poisson: dataCost must be > 0");
+    if (solver != GDPT_SOLVER_DCT && solver != GDPT_SOLVER_DCT_MFMA) throw std::runtime_error("poisson: unknown solver");
+    int dev = 0;
+    ck(hipGetDevice(&dev), "hipGetDevice");
+    StreamState &ss = stream_state(dev, stream);
+    std::lock_guard<std::mutex> lk(ss.mu);
+    const double *raw[5] = {img, cx0, cy0, cx1, cy1};
+    PoissonResult r = poisson_dct(dev, ss.dct, w, h, d_c, d_cx, d_cy, alpha, d_out, stream, timed, solver == GDPT_SOLVER_DCT, raw);
+    r.solver = solver;
+    return r;
 }
 
 PoissonResult poisson_solve_device(int w, int h, const double *d_c, const double *d_gx, const double *d_gy, double alpha,

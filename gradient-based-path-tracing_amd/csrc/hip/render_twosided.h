@@ -39,6 +39,10 @@ struct LanePriv2 {
 GD int n_iter(const Lane &L) { return (int)((unsigned)L.mats >> 12); }
 GD void set_n_iter(Lane &L, int n) { L.mats = (L.mats & 0xFFF) | (n << 12); }
 
+// Material set the kernel can be built for (bit t = material type t, include/gdpt.h): the test scenes pair ONE Disney lobe
+// with Lambertian walls, and a kernel that need not carry DisneyBSDF's five inlined lobes is a much smaller register
+// allocation problem (42 instead of 318 spilled VGPRs; +5 % on the glass scene).
+constexpr unsigned kSetGlass = (1u << GDPT_MAT_LAMBERTIAN) | (1u << GDPT_MAT_DISNEY_GLASS);
 template <unsigned MASK, class ACC>
 GD void lane_step2(const DevSceneView &sv, const TraceCtx &tx, int max_depth, double spp, int x, int y, unsigned long long base,
                    Lane &L, Trav &tv, LanePriv2 &lp, ACC &acc, LaneCounters &lc, BounceLog *log, int replay_per_step) {
@@ -117,46 +121,112 @@ GD void lane_step2(const DevSceneView &sv, const TraceCtx &tx, int max_depth, do
         } else off_done = true;                                                     // dead: contribX = 0, w = 1
     }
     if (st0 == S_REPLAY) off_alive = true;
-    if (off_alive) {
+    // The replay of the logged iterations and the base paths' BSDF block. SHARE: the FIRST re-sampling of a step runs through the
+    // shared block, in the same instructions as the base paths' bounces (a lane is either replaying or bouncing, and it is the same
+    // lobe code on the same kind of inputs: material of nv, a view direction, three numbers; the block's fused eval + pdf returns
+    // bsdf_pdf's bits); further iterations, up to the step's budget, follow in a loop of their own. Without it every iteration runs in
+    // that loop, and a wave executes the lobe code once per population and step. Same-box A/B
+    // (profiles/r03_ab_shared_bsdf_block.txt): the kernel with the full two-sided switch +6 % on DisneyBSDF (its offsets rarely outlive
+    // one iteration, so the loop is nearly emptied); the kernel built for {Lambertian, DisneyGlass} -10 % (43 -> 127 spilled VGPRs):
+    // that one keeps the separate loop. The two forms are written out side by side: expressed through shared helpers they compile
+    // to twice the spills of either (577 / 81 spilled VGPRs against 278 / 43).
+    constexpr bool SHARE = (MASK != kSetGlass);
+    bool sampled = false;
+    BsdfSample bs; bs.dir_out = splat(0); bs.eta = 0; bs.roughness = 0;
+    D3 f = splat(0);
+    double pdf = 0;
+    if (SHARE) {
+        const bool replaying = off_alive;
         int r = L.kc >> 2, budget = replay_per_step;
         const int n_it = n_iter(L);
         Pcg rs; rs.state = L.rng_state; rs.inc = L.rng_inc;
         D3 odir = L.f;
         double jac = L.pdf;
-        const GdptMaterial &om = tx.materials[nv.material_id];
-        for (;;) {
-            if (r >= n_it || r >= kLogCap) { off_done = true; off_alive = (r >= n_it); break; }       // all iterations replayed
-            const BounceLog e = log[r * kBlock];
-            if (nv.material_id != e.mat) { off_done = true; off_alive = false; break; }              // :607-612
-            if (e.p2 < 0) { off_done = true; break; }                               // the base broke at pdf <= 0: no re-sampling
-            if (budget-- == 0) { L.st = S_REPLAY; break; }
-            D2 ruv; double rw;
-            ruv.x = pcg_real(rs); ruv.y = pcg_real(rs); rw = pcg_real(rs);          // the base path's numbers of this iteration
-            if (r + 2 >= sv.rr_depth) (void)pcg_next(rs);                           // skip its roulette draw
-            BsdfSample obs; obs.dir_out = splat(0); obs.eta = 0; obs.roughness = 0;
-            const D3 oview = -odir;
-            const bool osampled = bsdf_sample<false, true, MASK>(sv, om, oview, nv, ruv, rw, obs);
-            const double opdf = osampled ? bsdf_pdf<false, true, MASK>(sv, om, oview, obs.dir_out, nv) : 0.0;
-            if (!osampled || opdf <= 0.0) { off_done = true; off_alive = false; break; }             // :773-959
-            jac *= e.p2 / opdf; odir = obs.dir_out; r++;                            // :813, :815-816
+        BounceLog e; e.p2 = 0; e.mat = 0; e.pad = 0;
+        D2 ruv; ruv.x = ruv.y = 0;
+        double rw = 0;
+        // head of a replay iteration: may this lane re-sample now? (draws the base path's numbers of iteration r if so)
+        auto replay_head = [&]() __attribute__((always_inline)) -> bool {
+            if (r >= n_it || r >= kLogCap) { off_done = true; off_alive = (r >= n_it); return false; }      // all iterations replayed
+            e = log[r * kBlock];
+            if (nv.material_id != e.mat) { off_done = true; off_alive = false; return false; }             // :607-612
+            if (e.p2 < 0) { off_done = true; return false; }                         // the base broke at pdf <= 0: no re-sampling
+            if (budget-- == 0) { L.st = S_REPLAY; return false; }
+            ruv.x = pcg_real(rs); ruv.y = pcg_real(rs); rw = pcg_real(rs);            // the base path's numbers of this iteration
+            if (r + 2 >= sv.rr_depth) (void)pcg_next(rs);                             // skip its roulette draw
+            return true;
+        };
+        const bool replay_now = replaying ? replay_head() : false;
+        // ---------------- shared BSDF block: base-path bounces and the first replay iteration of the step ----------------
+        if (act == ACT_BOUNCE) {
+            Pcg rb; rb.state = L.rng_state; rb.inc = L.rng_inc;
+            ruv.x = pcg_real(rb); ruv.y = pcg_real(rb); rw = pcg_real(rb);              // :536-537
+            L.rng_state = rb.state;
+            lc.bounces++;
         }
-        L.f = odir; L.pdf = jac; L.kc = (L.kc & 3) | (r << 2);
-        L.rng_state = rs.state;
-    }
-    // ---------------- shared BSDF block (base path) ----------------
-    bool sampled = false;
-    BsdfSample bs; bs.dir_out = splat(0); bs.eta = 0; bs.roughness = 0;
-    D3 f = splat(0);
-    double pdf = 0;
-    if (act == ACT_BOUNCE) {
-        D2 ruv; double rw;
-        Pcg r; r.state = L.rng_state; r.inc = L.rng_inc;
-        ruv.x = pcg_real(r); ruv.y = pcg_real(r); rw = pcg_real(r);                 // :536-537
-        L.rng_state = r.state;
-        lc.bounces++;
-        const D3 dir_view = -ray.dir;
-        sampled = mat_sample<false, false, true, MASK>(sv, tx, nv, dir_view, ruv, rw, bs);
-        if (sampled) mat_eval_pdf<false, false, true, MASK>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
+        if (act == ACT_BOUNCE || replay_now) {
+            const D3 dir_view = replay_now ? -odir : -ray.dir;
+            sampled = mat_sample<false, false, true, MASK>(sv, tx, nv, dir_view, ruv, rw, bs);
+            if (sampled) mat_eval_pdf<false, false, true, MASK>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
+        }
+        if (replay_now) {
+            const GdptMaterial &om = tx.materials[nv.material_id];
+            bool osampled = sampled;
+            double opdf = sampled ? pdf : 0.0;
+            D3 onext = bs.dir_out;
+            for (;;) {
+                if (!osampled || opdf <= 0.0) { off_done = true; off_alive = false; break; }             // :773-959
+                jac *= e.p2 / opdf; odir = onext; r++;                                  // :813, :815-816
+                if (!replay_head()) break;
+                BsdfSample obs; obs.dir_out = splat(0); obs.eta = 0; obs.roughness = 0;
+                const D3 oview = -odir;
+                osampled = bsdf_sample<false, true, MASK>(sv, om, oview, nv, ruv, rw, obs);
+                opdf = osampled ? bsdf_pdf<false, true, MASK>(sv, om, oview, obs.dir_out, nv) : 0.0;
+                onext = obs.dir_out;
+            }
+        }
+        if (replaying) {
+            L.f = odir; L.pdf = jac; L.kc = (L.kc & 3) | (r << 2);
+            L.rng_state = rs.state;
+        }
+    } else {
+        if (off_alive) {
+            int r = L.kc >> 2, budget = replay_per_step;
+            const int n_it = n_iter(L);
+            Pcg rs; rs.state = L.rng_state; rs.inc = L.rng_inc;
+            D3 odir = L.f;
+            double jac = L.pdf;
+            const GdptMaterial &om = tx.materials[nv.material_id];
+            for (;;) {
+                if (r >= n_it || r >= kLogCap) { off_done = true; off_alive = (r >= n_it); break; }       // all iterations replayed
+                const BounceLog e = log[r * kBlock];
+                if (nv.material_id != e.mat) { off_done = true; off_alive = false; break; }              // :607-612
+                if (e.p2 < 0) { off_done = true; break; }                               // the base broke at pdf <= 0: no re-sampling
+                if (budget-- == 0) { L.st = S_REPLAY; break; }
+                D2 ruv; double rw;
+                ruv.x = pcg_real(rs); ruv.y = pcg_real(rs); rw = pcg_real(rs);          // the base path's numbers of this iteration
+                if (r + 2 >= sv.rr_depth) (void)pcg_next(rs);                           // skip its roulette draw
+                BsdfSample obs; obs.dir_out = splat(0); obs.eta = 0; obs.roughness = 0;
+                const D3 oview = -odir;
+                const bool osampled = bsdf_sample<false, true, MASK>(sv, om, oview, nv, ruv, rw, obs);
+                const double opdf = osampled ? bsdf_pdf<false, true, MASK>(sv, om, oview, obs.dir_out, nv) : 0.0;
+                if (!osampled || opdf <= 0.0) { off_done = true; off_alive = false; break; }             // :773-959
+                jac *= e.p2 / opdf; odir = obs.dir_out; r++;                            // :813, :815-816
+            }
+            L.f = odir; L.pdf = jac; L.kc = (L.kc & 3) | (r << 2);
+            L.rng_state = rs.state;
+        }
+        // ---------------- shared BSDF block (base path) ----------------
+        if (act == ACT_BOUNCE) {
+            D2 ruv; double rw;
+            Pcg r; r.state = L.rng_state; r.inc = L.rng_inc;
+            ruv.x = pcg_real(r); ruv.y = pcg_real(r); rw = pcg_real(r);                 // :536-537
+            L.rng_state = r.state;
+            lc.bounces++;
+            const D3 dir_view = -ray.dir;
+            sampled = mat_sample<false, false, true, MASK>(sv, tx, nv, dir_view, ruv, rw, bs);
+            if (sampled) mat_eval_pdf<false, false, true, MASK>(sv, tx, nv, dir_view, bs.dir_out, f, pdf);
+        }
     }
     if (off_done) {
         const int k = L.k();
@@ -223,10 +293,6 @@ GD void lane_step2(const DevSceneView &sv, const TraceCtx &tx, int max_depth, do
     if (lane_tracing(L.st)) trav_init(sv, tv, __builtin_huge_val());      // a fresh pending ray (S_REPLAY keeps the offset's hit)
 }
 
-// Material set the kernel can be built for (bit t = material type t, include/gdpt.h): the test scenes pair ONE Disney lobe
-// with Lambertian walls, and a kernel that need not carry DisneyBSDF's five inlined lobes is a much smaller register
-// allocation problem (42 instead of 318 spilled VGPRs; +5 % on the glass scene).
-constexpr unsigned kSetGlass = (1u << GDPT_MAT_LAMBERTIAN) | (1u << GDPT_MAT_DISNEY_GLASS);
 template <bool LDS_SCENE, unsigned MASK = kAllMaterials>
 __global__ __launch_bounds__(kBlock, 2) void gdpt_render_twosided(DevSceneView sv, KernelArgs a, BounceLog *logs) {
     __shared__ int s_stack_fixed[LDS_SCENE ? kLdsSceneLevels * kBlock : 1];

@@ -283,10 +283,132 @@ std::vector<WideTmp> collapse_generic(const std::vector<DevBvhNode> &nodes, int 
     }
     return out;
 }
+
+// Cost-optimal collapse to four children (test knob bvh_collapse_dp): of all ways to pick the BVH2 nodes that survive as BVH4 nodes,
+// the one with the least summed surface area of BVH4 nodes — the expected number of node visits of a random line — among those whose
+// traversal stack stays within `stack_slots`. Dynamic programme over the BVH2, bottom-up (after Ylitie, Karras and Laine, "Efficient
+// incoherent ray traversal on GPUs through compressed wide BVHs", HPG 2017, section 3.1, with the stack budget as an extra index):
+//   W(n, b)    = cost of subtree n as a BVH4 node that may push b entries in total below itself
+//              = A(n) + min over c = 2..4 of Dist(n, c, b - (c - 1))         (c children cost c - 1 pushes; each child inherits the rest)
+//   D(n, j, b) = cost of subtree n as AT MOST j children of one BVH4 node, each with budget b:  D(n, 1, b) = W(n, b),
+//                D(n, j, b) = min(D(n, j - 1, b), Dist(n, j, b)),  Dist(n, j, b) = min over k of D(left, k, b) + D(right, j - k, b)
+// leaves cost nothing here (their count and boxes are fixed by the BVH2).
+std::vector<WideTmp> collapse_optimal4(const std::vector<DevBvhNode> &nodes, int stack_slots, int *stack_need) {
+    std::vector<WideTmp> out;
+    if (stack_need) *stack_need = 0;
+    if (nodes.empty()) return out;
+    const size_t N = nodes.size();
+    const int B = stack_slots + 1;                                   // budgets 0..stack_slots
+    for (const DevBvhNode &d : nodes) if (d.left == GDPT_CHILD_EMPTY || d.right == GDPT_CHILD_EMPTY) return out;   // (single-leaf tree: caller falls back)
+    const float INF = std::numeric_limits<float>::infinity();
+    std::vector<float> area(N, 0.f);
+    std::vector<int32_t> order;                                      // post-order of the inner nodes
+    {
+        std::vector<std::pair<int32_t, int>> st{{0, 0}};
+        while (!st.empty()) {
+            auto [ni, phase] = st.back(); st.pop_back();
+            const DevBvhNode &n = nodes[(size_t)ni];
+            if (phase == 0) { st.push_back({ni, 1}); if (n.left >= 0) st.push_back({n.left, 0}); if (n.right >= 0) st.push_back({n.right, 0}); }
+            else {
+                float lo[3], hi[3];
+                for (int k = 0; k < 3; k++) { lo[k] = std::min(n.lmin[k], n.rmin[k]); hi[k] = std::max(n.lmax[k], n.rmax[k]); }
+                const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+                area[(size_t)ni] = dx * dy + dy * dz + dz * dx;
+                order.push_back(ni);
+            }
+        }
+    }
+    // D[(n * 4 + (j - 1)) * B + b]; choice: kD = split k of Dist (0 = "use j - 1 roots"), cW = children count of W, kW = its split
+    std::vector<float> D(N * 4 * (size_t)B, INF);
+    std::vector<uint8_t> kD(N * 4 * (size_t)B, 0), cW(N * (size_t)B, 0), kW(N * (size_t)B, 0);
+    auto Dv = [&](int32_t child, int j, int b) -> float { return child < 0 ? 0.f : D[((size_t)child * 4 + (size_t)(j - 1)) * B + b]; };
+    for (int32_t ni : order) {
+        const DevBvhNode &n = nodes[(size_t)ni];
+        auto dist = [&](int j, int b, int *kbest) {
+            float best = INF; *kbest = 0;
+            for (int k = 1; k < j; k++) { const float v = Dv(n.left, k, b) + Dv(n.right, j - k, b); if (v < best) { best = v; *kbest = k; } }
+            return best;
+        };
+        // Dist(n, j, b) for j = 2..4 depends on the children only; W(n, b) needs Dist at smaller budgets: one ascending sweep does both
+        std::vector<float> distv(3 * (size_t)B, INF); std::vector<uint8_t> distk(3 * (size_t)B, 0);
+        for (int b = 0; b < B; b++)
+            for (int j = 2; j <= 4; j++) { int k; distv[(size_t)(j - 2) * B + b] = dist(j, b, &k); distk[(size_t)(j - 2) * B + b] = (uint8_t)k; }
+        for (int b = 0; b < B; b++) {
+            float w = INF; int wc = 0, wk = 0;
+            for (int c = 2; c <= 4; c++) {
+                const int bc = b - (c - 1);
+                if (bc < 0) break;
+                const float v = distv[(size_t)(c - 2) * B + bc];
+                if (v < w) { w = v; wc = c; wk = distk[(size_t)(c - 2) * B + bc]; }
+            }
+            const size_t base = ((size_t)ni * 4) * B;
+            D[base + b] = (w < INF) ? area[(size_t)ni] + w : INF;
+            cW[(size_t)ni * B + b] = (uint8_t)wc; kW[(size_t)ni * B + b] = (uint8_t)wk;
+            for (int j = 2; j <= 4; j++) {
+                const float prev = D[base + (size_t)(j - 2) * B + b], dv = distv[(size_t)(j - 2) * B + b];
+                if (dv < prev) { D[base + (size_t)(j - 1) * B + b] = dv; kD[base + (size_t)(j - 1) * B + b] = distk[(size_t)(j - 2) * B + b]; }
+                else { D[base + (size_t)(j - 1) * B + b] = prev; kD[base + (size_t)(j - 1) * B + b] = 0; }
+            }
+        }
+    }
+    if (!(D[(size_t)stack_slots] < INF)) return out;                 // (the BVH2 is deeper than the stack: caller falls back)
+    // top-down: a queue of (BVH2 node, budget) that become BVH4 nodes, breadth-first
+    struct Item { int32_t node; int budget; };
+    std::vector<Item> queue{{0, stack_slots}};
+    out.emplace_back();
+    struct Ref { float lo[3], hi[3]; int32_t child; };
+    for (size_t qi = 0; qi < queue.size(); qi++) {
+        const int32_t ni = queue[qi].node; const int b = queue[qi].budget;
+        const int c = cW[(size_t)ni * B + b], bc = b - (c - 1);
+        Ref refs[4]; int cnt = 0;
+        // expand (subtree, j roots) pairs; `box` of a subtree comes from its parent's record
+        struct Todo { int32_t sub; int j; float lo[3], hi[3]; };
+        std::vector<Todo> todo;
+        auto push_children = [&](int32_t p, int k, int j) {        // children of BVH2 node p: left gets k roots, right j - k
+            const DevBvhNode &n = nodes[(size_t)p];
+            Todo r; r.sub = n.right; r.j = j - k; for (int x = 0; x < 3; x++) { r.lo[x] = n.rmin[x]; r.hi[x] = n.rmax[x]; }
+            Todo l; l.sub = n.left; l.j = k; for (int x = 0; x < 3; x++) { l.lo[x] = n.lmin[x]; l.hi[x] = n.lmax[x]; }
+            todo.push_back(r); todo.push_back(l);
+        };
+        push_children(ni, kW[(size_t)ni * B + b], c);
+        while (!todo.empty()) {
+            Todo t = todo.back(); todo.pop_back();
+            if (t.sub < 0) { Ref r; r.child = t.sub; for (int x = 0; x < 3; x++) { r.lo[x] = t.lo[x]; r.hi[x] = t.hi[x]; } refs[cnt++] = r; continue; }
+            int j = t.j;
+            while (j > 1 && kD[((size_t)t.sub * 4 + (size_t)(j - 1)) * B + bc] == 0) j--;      // "at most j": fewer roots were as cheap
+            if (j == 1) { Ref r; r.child = t.sub; for (int x = 0; x < 3; x++) { r.lo[x] = t.lo[x]; r.hi[x] = t.hi[x]; } refs[cnt++] = r; continue; }
+            push_children(t.sub, kD[((size_t)t.sub * 4 + (size_t)(j - 1)) * B + bc], j);
+        }
+        WideTmp nd;
+        for (int cc = 0; cc < 8; cc++) {
+            for (int k = 0; k < 3; k++) { nd.lo[k][cc] = std::numeric_limits<float>::infinity(); nd.hi[k][cc] = -std::numeric_limits<float>::infinity(); }
+            nd.child[cc] = GDPT_CHILD_EMPTY;
+        }
+        nd.cnt = cnt;
+        for (int cc = 0; cc < cnt; cc++) {
+            for (int k = 0; k < 3; k++) { nd.lo[k][cc] = refs[cc].lo[k]; nd.hi[k][cc] = refs[cc].hi[k]; }
+            if (refs[cc].child >= 0) { nd.child[cc] = (int32_t)out.size(); queue.push_back({refs[cc].child, bc}); out.emplace_back(); }
+            else nd.child[cc] = refs[cc].child;
+        }
+        out[qi] = nd;
+    }
+    if (stack_need) {
+        std::vector<int> need(out.size(), 0);
+        for (size_t i = out.size(); i-- > 0;) {
+            int cnt = 0, sub = 0;
+            for (int c = 0; c < 8; c++) if (out[i].child[c] != GDPT_CHILD_EMPTY) { cnt++; if (out[i].child[c] >= 0) sub = std::max(sub, need[(size_t)out[i].child[c]]); }
+            need[i] = std::max(0, cnt - 1) + sub;
+        }
+        *stack_need = need[0];
+    }
+    return out;
+}
 } // namespace
 
 std::vector<DevBvh4Node> collapse_bvh4(const std::vector<DevBvhNode> &nodes, int max_children, int stack_slots, int *stack_need) {
-    std::vector<WideTmp> tmp = collapse_generic(nodes, std::min(4, max_children), stack_slots, stack_need);
+    std::vector<WideTmp> tmp;
+    if (max_children >= 4 && debug_knob_int("bvh_collapse_dp", 0) != 0) tmp = collapse_optimal4(nodes, stack_slots, stack_need);
+    if (tmp.empty()) tmp = collapse_generic(nodes, std::min(4, max_children), stack_slots, stack_need);
     std::vector<DevBvh4Node> out(tmp.size());
     for (size_t i = 0; i < tmp.size(); i++) {
         DevBvh4Node &nd = out[i];

@@ -192,13 +192,15 @@ class ShardedGradPath:
         solve(c, cx, cy, out, want_stats)     fourierSolve, src/render.cpp:172-254
         new_image()                           a zeroed HxWx3 float64 tensor on the rank's device
         phase_hook(name)                      optional; called after 'render', 'exchange', 'solve' (per-phase timing)
+        assemble_solve(bufs, (c, cx, cy), out, want_stats)   optional; one rank only: assemble + solve as one call
+                                              (gdpt_assemble_solve_device: one pass over the film instead of two, same bits)
 
     `dist` is torch.distributed (any backend) or None when world == 1.
     """
 
     NAMES = ("img", "cx0", "cy0", "cx1", "cy1")
 
-    def __init__(self, dist, world, rank, height, new_image, render_band, assemble, solve, phase_hook=None, bands=None):
+    def __init__(self, dist, world, rank, height, new_image, render_band, assemble, solve, phase_hook=None, bands=None, assemble_solve=None):
         self.dist, self.world, self.rank, self.height = dist, int(world), int(rank), int(height)
         # `bands`: every rank's rows (the same list on all ranks), e.g. bands_weighted(...); default: equal tile-row counts
         self.bands = [tuple(b) for b in bands] if bands is not None else all_bands(self.height, self.world)
@@ -206,6 +208,7 @@ class ShardedGradPath:
             raise ValueError("bands must be contiguous, rank-ordered and cover the film")
         self.rows = self.bands[self.rank]
         self.render_band, self.assemble, self.solve = render_band, assemble, solve
+        self.assemble_solve = assemble_solve if self.world == 1 else None
         self.phase_hook = phase_hook or (lambda name: None)
         self.bufs = {k: new_image() for k in self.NAMES}
         self.c, self.cx, self.cy, self.out = (new_image() for _ in range(4))
@@ -215,6 +218,11 @@ class ShardedGradPath:
         r0, r1 = self.rows
         rstats = self.render_band(self.bufs, self.rows, want_stats) if r1 > r0 else None
         self.phase_hook("render")
+        if self.assemble_solve is not None:       # the whole film is here: no exchange, assembly rides on the solve's first pass
+            self.phase_hook("exchange")
+            pstats = self.assemble_solve(self.bufs, (self.c, self.cx, self.cy), self.out, want_stats)
+            self.phase_hook("solve")
+            return rstats, pstats
         if self.world > 1:            # exchange 1: the last cy1 row of the band above (W*24 bytes, point to point)
             halo_exchange_cy1(self.dist, self.bufs["cy1"], self.height, self.world, self.rank, self.bands)
         if r1 > r0:

@@ -264,6 +264,18 @@ int gdpt_poisson_solve_device(int width, int height,
                               int solver, double tol, int max_iters,
                               void *stream, GdptPoissonStats *stats /* nullable */);
 
+/* gdpt_assemble_device followed by gdpt_poisson_solve_device on its outputs — what gradient_path_render does after the tile loop
+ * (src/render.cpp:340-353) — as one call for a film that sits whole on one device: with the DCT solvers the assembly and the
+ * right-hand side of the solve are one pass over the film. d_c / d_cx / d_cy are written as gdpt_assemble_device writes them; every
+ * result has the bits of the two separate calls. Enqueue-only unless `stats` (as gdpt_poisson_solve_device). */
+int gdpt_assemble_solve_device(int width, int height,
+                               const double *d_img, const double *d_cx0, const double *d_cy0,
+                               const double *d_cx1, const double *d_cy1,
+                               double *d_c, double *d_cx, double *d_cy,
+                               double dataCost, double *d_out,
+                               int solver, double tol, int max_iters,
+                               void *stream, GdptPoissonStats *stats /* nullable */);
+
 /* Drops the solver scratch the library keeps for `stream` on the current device (buffers, handles, events). Owners of a
  * stream call it before destroying the stream, with no solve in flight on it; a stream the library never saw is fine. */
 int gdpt_poisson_forget_stream(void *stream);

@@ -20,7 +20,7 @@ for name, rel, w, h, integ, spp in cases:
     sd = G.parse_scene(scene_variant(tmp, rel, width=w, height=h, integrator=integ))
     scs = {}
     for mode in (0, on):
-        with G.debug_knobs(**{knob: mode}, **(extra if mode else {})):
+        with G.debug_knobs(**({knob: mode, **extra} if mode else {})):      # baseline: no knob set at all (the product path)
             scs[mode] = G.Scene(sd)
     res, bufs, sts = {}, {}, {}
     for rep in range(5):
@@ -28,5 +28,5 @@ for name, rel, w, h, integ, spp in cases:
             b, st = scs[mode].render(spp, G.RNG_SAMPLE)
             res.setdefault(mode, []).append(st.render_ms); bufs[mode] = b; sts[mode] = st
     same = all(np.array_equal(bufs[0][k], bufs[on][k], equal_nan=True) for k in bufs[0])
-    print(f"{name}: {extra if extra else ''} {knob}=0 {min(res[0]):.3f} ms ({st.samples / min(res[0]) / 1e3:.1f} Msamples/s) | {knob}={on} {min(res[on]):.3f} ms "
+    print(f"{name}: {extra if extra else ''} default {min(res[0]):.3f} ms ({st.samples / min(res[0]) / 1e3:.1f} Msamples/s) | {knob}={on} {min(res[on]):.3f} ms "
           f"({st.samples / min(res[on]) / 1e3:.1f} Msamples/s) | buffers identical: {same}", flush=True)

@@ -2,6 +2,7 @@
 golden vectors, and size-independent properties at BASELINE.json's full size."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -87,6 +88,16 @@ def test_poisson_bad_arguments(G):
     z = np.zeros((4, 4, 3))
     with pytest.raises(G.GdptError):
         G.fourierSolve(4, 4, z, z, z, 0.0)
+
+
+def test_assembly_fused_with_the_solve_gives_the_bits_of_the_two_calls():
+    """gdpt_assemble_solve_device: assembly (src/render.cpp:340-350) and the solver's right-hand side (:213-224) as one pass over
+    the film. c / cx / cy and the reconstruction must equal gdpt_assemble_device + gdpt_poisson_solve_device bit for bit, for every
+    solver and for ragged, tiny and full-size films. (Own process: the device buffers are torch tensors, and torch has to bring up
+    the GPU before the library does — as in bench.py.)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_fused_solve_child.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ALL EQUAL" in r.stdout and r.stdout.count("equal:") == 18
 
 
 def test_full_pipeline_small(G, O, scene_tmp):
