@@ -346,16 +346,31 @@ int gdpt_multi_create(const GdptSceneDesc *desc, const GdptMultiConfig *cfg, Gdp
         const size_t elems = (size_t)m->w * m->h * 3;
         bool equal = true;
         std::vector<int> first_tile;                 // cfg->balance: bands by the measured cost of their tile rows
+        {   // every device gets its own copy of the scene; the host side of an upload (tree build with spatial splits, mip chains) is
+            // seconds for a large mesh, so the N uploads run side by side instead of one after the other
+            std::vector<std::exception_ptr> errs((size_t)n);
+            std::vector<std::thread> th;
+            auto one = [&](int i) {
+                try {
+                    Rank &r = m->ranks[(size_t)i];
+                    r.device = cfg->devices[i];
+                    r.scene.reset(new GdptScene());
+                    gdpt::build_scene(desc, r.device, r.scene.get());       // sets the calling thread's device
+                    r.scene->scene_spp = desc->samples_per_pixel;
+                } catch (...) { errs[(size_t)i] = std::current_exception(); }
+            };
+            for (int i = 1; i < n; i++) th.emplace_back(one, i);
+            one(0);
+            for (std::thread &t : th) t.join();
+            for (const std::exception_ptr &e : errs) if (e) std::rethrow_exception(e);
+        }
         for (int i = 0; i < n; i++) {
             Rank &r = m->ranks[(size_t)i];
-            r.device = cfg->devices[i];
+            ck(hipSetDevice(r.device), "hipSetDevice");
             if (cfg->balance && n > 1 && i > 0) {
                 r.row_begin = std::min(first_tile[(size_t)i] * kTile, m->h); r.row_end = std::min(first_tile[(size_t)i + 1] * kTile, m->h);
             } else band_rows(m->h, n, i, &r.row_begin, &r.row_end);
             if (r.row_end - r.row_begin != m->ranks[0].row_end - m->ranks[0].row_begin || r.row_end <= r.row_begin) equal = false;
-            r.scene.reset(new GdptScene());
-            gdpt::build_scene(desc, r.device, r.scene.get());       // sets the device
-            r.scene->scene_spp = desc->samples_per_pixel;
             if (cfg->balance && n > 1 && i == 0) {    // pilot on the first device: rays per tile row at 1 spp (exact counts: every caller sees the same bands)
                 const int T = (m->h + kTile - 1) / kTile;
                 std::vector<double> cost((size_t)T);

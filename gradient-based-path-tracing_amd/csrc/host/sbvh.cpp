@@ -12,7 +12,9 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <exception>
 #include <stdexcept>
+#include <thread>
 #include <utility>
 
 namespace gdpt {
@@ -268,6 +270,22 @@ struct SBuilder {
         l.assign(refs.begin(), refs.begin() + (std::ptrdiff_t)m); r.assign(refs.begin() + (std::ptrdiff_t)m, refs.end());
     }
 
+    static constexpr int kForkLevels = 3;          // the top three levels fork: up to eight subtrees in flight
+    static constexpr size_t kForkMin = 4096;
+    // Appends a sub-builder's nodes and leaf slots to this builder's; returns the sub-root's reference in this builder's numbering.
+    int32_t adopt(SBuilder &sb, const std::vector<uint32_t> &rp, int32_t code) {
+        const int32_t node_off = (int32_t)out.nodes.size();
+        const uint32_t slot_off = (uint32_t)ref_prim->size();
+        auto fix = [&](int32_t c) -> int32_t {
+            if (c == GDPT_CHILD_EMPTY) return c;
+            if (c >= 0) return c + node_off;
+            const uint32_t packed = ~(uint32_t)c;
+            return ~(int32_t)((((packed >> 2) + slot_off) << 2) | (packed & 3u));
+        };
+        for (DevBvhNode nd : sb.out.nodes) { nd.left = fix(nd.left); nd.right = fix(nd.right); out.nodes.push_back(nd); }
+        for (uint32_t p : rp) { out.order.push_back((uint32_t)ref_prim->size()); ref_prim->push_back(p); }
+        return fix(code);
+    }
     int32_t build_inner(std::vector<SRef> &refs, int level, int *depth_out) {
         const int32_t me = (int32_t)out.nodes.size();
         out.nodes.emplace_back();
@@ -282,8 +300,33 @@ struct SBuilder {
         std::vector<SRef>().swap(refs);
         const SBox lb = box_of(l), rb = box_of(r);
         int dl = 0, dr = 0;
-        const int32_t cl = build_child(l, level + 1, &dl);
-        const int32_t cr = build_child(r, level + 1, &dr);
+        int32_t cl, cr;
+        if (level < kForkLevels && l.size() >= kForkMin && r.size() >= kForkMin) {
+            // The two subtrees are built side by side by builders of their own (the reference's Embree build is parallel too), each
+            // with its share of the reference budget, and appended left then right — the node and leaf numbering a depth-first
+            // build would give, whatever the threads' timing.
+            SBuilder sub[2] = {SBuilder(tv, nullptr), SBuilder(tv, nullptr)};
+            std::vector<uint32_t> rp[2];
+            std::vector<SRef> *part[2] = {&l, &r};
+            int32_t code[2] = {0, 0};
+            int depth[2] = {0, 0};
+            const long long share_l = (long long)((double)spare * (double)l.size() / (double)(l.size() + r.size()));
+            for (int c = 0; c < 2; c++) {
+                sub[c].ref_prim = &rp[c]; sub[c].root_area = root_area; sub[c].alpha = alpha; sub[c].leaf_max = leaf_max; sub[c].leaf_factor = leaf_factor;
+                sub[c].spare = c == 0 ? share_l : spare - share_l;
+            }
+            std::exception_ptr err;
+            std::thread other([&]() { try { code[1] = sub[1].build_child(*part[1], level + 1, &depth[1]); } catch (...) { err = std::current_exception(); } });
+            try { code[0] = sub[0].build_child(*part[0], level + 1, &depth[0]); } catch (...) { other.join(); throw; }
+            other.join();
+            if (err) std::rethrow_exception(err);
+            spare = sub[0].spare + sub[1].spare;
+            cl = adopt(sub[0], rp[0], code[0]); cr = adopt(sub[1], rp[1], code[1]);
+            dl = depth[0]; dr = depth[1];
+        } else {
+            cl = build_child(l, level + 1, &dl);
+            cr = build_child(r, level + 1, &dr);
+        }
         DevBvhNode &nd = out.nodes[(size_t)me];
         for (int k = 0; k < 3; k++) { nd.lmin[k] = lb.lo[k]; nd.lmax[k] = lb.hi[k]; nd.rmin[k] = rb.lo[k]; nd.rmax[k] = rb.hi[k]; }
         nd.left = cl; nd.right = cr; nd.pad[0] = nd.pad[1] = 0;
