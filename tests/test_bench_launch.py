@@ -50,3 +50,35 @@ def test_bench_refuses_more_ranks_than_gpus():
     assert r.returncode != 0
     assert f"needs {n + 2} GPUs" in r.stderr and "visible" in r.stderr
     assert not r.stdout.strip()                      # no JSON line pretending to be a measurement
+
+
+def test_one_rank_takes_the_fused_assembly_and_solve_and_several_ranks_do_not():
+    """ShardedGradPath(assemble_solve=...): with one rank the whole film is local, so assembly and solve go through the one fused
+    call (gdpt_assemble_solve_device in bench.py) and the phase hooks still fire in order; with several ranks the bands have to
+    be gathered between the two, so the hook is ignored. Host logic only: the phases are stand-ins."""
+    import torch
+    from gdpt_amd import sharding
+    calls = []
+
+    def render_band(bufs, rows, want_stats):
+        calls.append(("render", rows)); bufs["img"][rows[0]:rows[1]] = 1.0
+
+    def assemble(bufs, dst, rows):
+        calls.append(("assemble", rows))
+
+    def solve(c, cx, cy, out, want_stats):
+        calls.append(("solve",)); return "separate"
+
+    def assemble_solve(bufs, dst, out, want_stats):
+        calls.append(("assemble_solve",)); out.copy_(bufs["img"]); return "fused"
+
+    new = lambda: torch.zeros((32, 8, 3), dtype=torch.float64)
+    pipe = sharding.ShardedGradPath(None, 1, 0, 32, new, render_band, assemble, solve, phase_hook=lambda n: calls.append(("hook", n)), assemble_solve=assemble_solve)
+    _, pstats = pipe.step()
+    assert pstats == "fused" and float(pipe.out.sum()) == 32 * 8 * 3
+    assert calls == [("render", (0, 32)), ("hook", "render"), ("hook", "exchange"), ("assemble_solve",), ("hook", "solve")]
+    calls.clear()
+    pipe = sharding.ShardedGradPath(None, 1, 0, 32, new, render_band, assemble, solve)
+    assert pipe.step()[1] == "separate" and [c[0] for c in calls] == ["render", "assemble", "solve"]
+    two = sharding.ShardedGradPath(object(), 2, 1, 32, new, render_band, assemble, solve, assemble_solve=assemble_solve)
+    assert two.assemble_solve is None and two.rows == (16, 32)
