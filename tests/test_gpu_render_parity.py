@@ -277,21 +277,23 @@ def test_two_sided_lane_machine_replays_offsets_exactly(G, O, scene_tmp, scene, 
     assert np.abs(want["cx0"]).max() > 0
 
 
-@pytest.mark.parametrize("rel, integ", [("sponza/sponza.xml", None), ("disney_bsdf_test/disney_metal.xml", "gradpath")])
+@pytest.mark.parametrize("rel, integ", [("sponza/sponza.xml", None), ("disney_bsdf_test/disney_metal.xml", "gradpath"), ("cbox/cbox_gdpt.xml", None)])
 def test_closest_hit_does_not_depend_on_the_tree(G, scene_tmp, rel, integ, monkeypatch):
     """The hit a ray reports is defined without reference to the BVH (fp32 Möller–Trumbore, smallest t, lowest primitive id
-    on ties), so two different trees over the same triangles must give bit-identical images. The second tree comes from
-    the pre-split knob (host/presplit.cpp: large triangles referenced from several clipped boxes) and a different leaf
-    policy — a traversal that skipped a box it should have entered, or a clipped box that lost part of its triangle,
-    shows up here as a differing pixel."""
+    on ties), so different trees over the same triangles must give bit-identical images. Four trees: the product's (SAH with
+    spatial splits, host/sbvh.cpp: triangles referenced from every leaf that holds a part of them), the same with another leaf
+    policy, the object-split build (the product's for small scenes such as cbox), the object-split build over pre-split triangles
+    (host/presplit.cpp), and spatial splits under a tight reference budget — a traversal that
+    skipped a box it should have entered, or a clipped box that lost part of its triangle, shows up here as a differing pixel."""
     xml = scene_variant(scene_tmp, rel, width=160, height=96, integrator=integ)
     sd = G.parse_scene(xml)
     a, sa = G.Scene(sd).render(4, G.RNG_SAMPLE)
-    with G.debug_knobs(presplit=0.7, bvh_leaf_max=2):
-        b, sb = G.Scene(sd).render(4, G.RNG_SAMPLE)
-    for k in BUFS:
-        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k]), equal_nan=True), k
-    assert sa.rays == sb.rays and sa.bounces == sb.bounces
+    for knobs in ({"bvh_leaf_max": 2}, {"sbvh": 0.0}, {"sbvh": 0.0, "presplit": 0.7, "bvh_leaf_max": 2}, {"sbvh": 0.15, "sbvh_alpha": 0.0}, {"sbvh": 1.0}):
+        with G.debug_knobs(**knobs):
+            b, sb = G.Scene(sd).render(4, G.RNG_SAMPLE)
+        for k in BUFS:
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k]), equal_nan=True), (k, knobs)
+        assert sa.rays == sb.rays and sa.bounces == sb.bounces
 
 
 def test_kernel_without_sphere_and_texture_code_equals_the_general_one(G, scene_tmp):
