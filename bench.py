@@ -6,7 +6,7 @@ gradient assembly -> screened-Poisson solve, with the scene (BVH, triangles, mat
 in HBM when the timed region starts.
 
 N = 1: BASELINE.json configs[1] — cbox_gdpt geometry, 512x512, 16 spp, one MI355X.
-N > 1: the film is sharded into N contiguous bands of whole tile rows; every rank renders its band,
+N > 1: the film is sharded into N contiguous row bands; every rank renders its band,
        sends the last cy1 row to the rank below, assembles c, cx, cy for its band, an in-place all-gather (RCCL) puts
        the three images on every rank, then the solve runs replicated — `gdpt_amd.sharding.ShardedGradPath.step`, the
        same object the gloo tests drive on CPU tensors. No collective inside the render.
@@ -77,9 +77,11 @@ def parse_args(argv=None):
                     help="nccl = RCCL (the measured configuration). gloo = rehearsal of the N>1 step where fewer than N GPUs "
                          "exist: ranks share the visible devices and the exchange is staged through host memory; the line "
                          "is marked \"rehearsal\" and is not a measurement")
-    ap.add_argument("--bands", choices=("cost", "equal"), default="cost",
+    ap.add_argument("--bands", choices=("feedback", "cost", "equal"), default="feedback",
                     help="N>1: 'cost' = row bands of equal measured cost (a 1-spp pilot counts the rays of every tile row; exact "
-                         "counts, so every rank cuts the same bands), 'equal' = equal tile-row counts")
+                         "counts, so every rank cuts the same bands, run after run); 'feedback' = the same, then corrected twice during "
+                         "the warm-up by every rank's own render time of a frame (all-gathered, so the ranks still agree; the bands then "
+                         "depend on the clock); 'equal' = equal tile-row counts")
     ap.add_argument("--plan-bands", type=int, default=0,
                     help="cut every pixel's samples into work items as for this many row bands (default: --gpus); a 1-GPU run with "
                          "--plan-bands N produces the N-GPU run's images bit for bit (GdptRenderParams.plan_rows)")
@@ -215,10 +217,10 @@ def run_rank(args):
 
     # work items are cut for the largest band of the sharding (the same on every rank): GdptRenderParams.plan_rows
     plan_bands = args.plan_bands if args.plan_bands > 0 else world
-    tile_costs = scene.tile_row_costs() if args.bands == "cost" and max(world, plan_bands) > 1 else None
+    tile_costs = scene.tile_row_costs() if args.bands in ("cost", "feedback") and max(world, plan_bands) > 1 else None
 
-    def cut(n):
-        return sharding.bands_weighted(H, n, tile_costs) if tile_costs is not None and n > 1 else sharding.all_bands(H, n)
+    def cut(n):        # cuts at any row: the SAMPLE streams do not need whole tile rows (items are anchored at the band's first row)
+        return sharding.bands_weighted(H, n, tile_costs, granularity=1) if tile_costs is not None and n > 1 else sharding.all_bands(H, n)
     bands = cut(world)
     plan_rows = max(b[1] - b[0] for b in cut(plan_bands))
 
@@ -287,9 +289,47 @@ def run_rank(args):
             out = dict(zip(("render", "exchange", "solve"), [float(x) for x in t.tolist()]))
         return out
 
+    def local_render_ms(pipe, reps):
+        """This rank's own render time of a step (events on the launch stream): best of `reps`."""
+        best = 1e30
+        for _ in range(reps):
+            got = {}
+            pipe.phase_hook = lambda name: got.setdefault(name, _rec())
+
+            def _rec():
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                return e
+            e0 = _rec()
+            pipe.step()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(got["render"]))
+        pipe.phase_hook = lambda name: None
+        return best
+
     # ---- the timed region: weak scaling, args.spp per GPU
     spp_total = args.spp * world
     pipe = make_pipeline(spp_total)
+    band_feedback = None
+    if world > 1 and args.bands == "feedback" and tile_costs is not None:
+        # The pilot counts rays; what a ray costs where, it does not know (the lower half of the cbox film is 10 % dearer per ray:
+        # profiles/r03_band_costs.txt). Two rounds of feedback from the frame's own clock, before anything is timed: every rank
+        # measures its band, the times are all-gathered, every rank rescales the cost model band by band and cuts again.
+        row_costs = sharding.row_costs_from_tiles(H, tile_costs)
+        band_feedback = {"rounds": 2, "rows": [[b[1] - b[0] for b in bands]], "render_ms_per_rank": []}
+        for _ in range(2):
+            pipe.step()
+            mine = torch.tensor([local_render_ms(pipe, 2)], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            times = [float(t.item()) for t in every]
+            row_costs = sharding.refine_row_costs(row_costs, bands, times)
+            bands = sharding.bands_from_row_costs(H, world, row_costs)
+            if plan_bands == world:
+                plan_rows = max(b[1] - b[0] for b in bands)
+            band_feedback["render_ms_per_rank"].append([round(t, 4) for t in times])
+            band_feedback["rows"].append([b[1] - b[0] for b in bands])
+            pipe = make_pipeline(spp_total)
     r0, r1 = pipe.rows
     elapsed = timed(pipe, args.steps, args.warmup)
     ph = phases(pipe, max(3, min(args.steps, 10)))
@@ -372,7 +412,7 @@ def run_rank(args):
                                f"({spp_total} spp total), render+assemble+Poisson(DCT-I as folded fp64 MFMA GEMMs, own kernels) per step"
                                + (" [shift=reconnect: extension mode, NOT the headline workload]" if args.shift == "reconnect" else ""),
                    "rng": "sample-stream PCG32",
-                   "sharding": (f"{world} row bands ({'equal measured cost: rows ' + ' '.join(str(b[1] - b[0]) for b in bands) if tile_costs is not None else 'equal tile-row counts'}), "
+                   "sharding": (f"{world} row bands ({('equal measured cost' + (' (pilot + two rounds of time feedback)' if band_feedback else ' (pilot)') + ': rows ' + ' '.join(str(b[1] - b[0]) for b in bands)) if tile_costs is not None else 'equal tile-row counts'}), "
                                 f"1-row halo + in-place all-gather / per-band broadcast of c,cx,cy ({args.dist_backend})") if world > 1 else "single GPU",
                    "alpha": args.alpha},
         "render_ms": render_ms, "exchange_ms": ph["exchange"], "poisson_ms": ph["solve"],
@@ -382,6 +422,7 @@ def run_rank(args):
         "nonfinite_samples": int(rs.nonfinite_samples) if rs is not None else None,
         "scaling_strong": strong,
         "pipelined": pipelined,
+        "band_feedback": band_feedback,
     }
     if rehearsal:
         result["rehearsal"] = (f"{world} ranks on {ndev} visible GPU(s), exchange staged through host memory over gloo: exercises the "

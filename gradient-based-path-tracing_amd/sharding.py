@@ -41,39 +41,86 @@ def all_bands(height, world):
     return [band_rows(height, world, r) for r in range(world)]
 
 
-def bands_weighted(height, world, costs):
-    """Bands of whole tile rows whose largest COST is as small as a contiguous split allows; `costs[t]` >= 0 is the measured
-    cost of tile row t (Scene.tile_row_costs: rays of a pilot render). Linear partition by dynamic programming, ties to the
-    split found first — the mirror of gdpt_band_rows_weighted (csrc/hip/multi_gpu.hip), cut for cut. With fewer tile rows than
-    ranks the last ranks own nothing, as in band_rows."""
+def bands_weighted(height, world, costs, granularity=TILE):
+    """Contiguous bands whose largest COST is as small as a contiguous split allows; `costs[t]` >= 0 is the measured cost of tile
+    row t (Scene.tile_row_costs: rays of a pilot render), spread evenly over the tile row's pixel rows. Cuts fall on multiples of
+    `granularity` rows (16, the default: whole tile rows, as GDPT_RNG_TILE needs them — the mirror of gdpt_band_rows_weighted,
+    csrc/hip/multi_gpu.hip, cut for cut; 1: any row — the persistent kernels anchor their 16x16 items at the band's first row, so
+    a band of the SAMPLE streams need not consist of whole tile rows: what bench.py uses). Linear partition by dynamic programming
+    over (bands, units), ties to the split found first. With fewer units than ranks the last ranks own nothing, as in band_rows."""
+    return bands_from_row_costs(height, world, row_costs_from_tiles(height, costs), granularity)
+
+
+def row_costs_from_tiles(height, costs):
+    """Per-row costs from per-tile-row costs: a tile row's cost spread evenly over its rows (the last tile row may be short)."""
     T = (height + TILE - 1) // TILE
     if len(costs) != T:
         raise ValueError("one cost per 16-pixel tile row expected")
     if any(not (c >= 0.0) for c in costs):
         raise ValueError("negative or non-finite cost")
-    used = min(world, T)
+    out = []
+    for t in range(T):
+        rows = min(height, t * TILE + TILE) - t * TILE
+        out.extend([float(costs[t]) / float(rows)] * rows)
+    return out
+
+
+def bands_from_row_costs(height, world, row_costs, granularity=1):
+    """The linear partition behind bands_weighted on per-row costs (len(row_costs) == height)."""
+    import numpy as np
+    if len(row_costs) != height:
+        raise ValueError("one cost per pixel row expected")
+    if any(not (c >= 0.0) for c in row_costs):
+        raise ValueError("negative or non-finite cost")
+    g = int(granularity)
+    if g < 1 or TILE % g != 0:
+        raise ValueError("granularity must divide the tile height")
+    U = (height + g - 1) // g                               # units of g rows (the last may be shorter)
     pre = [0.0]
-    for c in costs:
-        pre.append(pre[-1] + float(c))
+    for u in range(U):
+        c = 0.0
+        for r in range(u * g, min(height, u * g + g)):
+            c += float(row_costs[r])
+        pre.append(pre[-1] + c)
+    pre = np.asarray(pre, dtype=np.float64)
+    used = min(world, U)
     inf = 1e300
-    best = [[inf] * (T + 1) for _ in range(used + 1)]
-    cut = [[0] * (T + 1) for _ in range(used + 1)]
+    best = np.full((used + 1, U + 1), inf)
+    cut = np.zeros((used + 1, U + 1), dtype=np.int64)
     best[0][0] = 0.0
     for k in range(1, used + 1):
-        for t in range(k, T - (used - k) + 1):
-            for s in range(k - 1, t):
-                if best[k - 1][s] >= inf:
-                    continue
-                v = max(best[k - 1][s], pre[t] - pre[s])
-                if v < best[k][t]:
-                    best[k][t], cut[k][t] = v, s
-    first = [T] * (world + 1)
-    t = T
+        for t in range(k, U - (used - k) + 1):
+            v = np.maximum(best[k - 1][k - 1:t], pre[t] - pre[k - 1:t])
+            v = np.where(best[k - 1][k - 1:t] >= inf, inf, v)
+            i = int(np.argmin(v))                           # first minimum: the split found first
+            if v[i] < best[k][t]:
+                best[k][t], cut[k][t] = v[i], k - 1 + i
+    first = [U] * (world + 1)
+    t = U
     for k in range(used, 0, -1):
         first[k] = t
-        t = cut[k][t]
+        t = int(cut[k][t])
     first[0] = 0
-    return [(min(first[r] * TILE, height), min(first[r + 1] * TILE, height)) for r in range(world)]
+    return [(min(first[r] * g, height), min(first[r + 1] * g, height)) for r in range(world)]
+
+
+def refine_row_costs(row_costs, bands, times):
+    """Feedback for the next frames: `times[b]` = measured render time of band b = rows bands[b] under the cost model `row_costs`.
+    Returns the model with every band's rows rescaled so that the band's modelled cost is proportional to its measured time (the
+    pilot's ray counts miss what a ray costs where; a frame's own clock does not). Bands without rows or without a time keep theirs.
+    Every rank must pass the same `times` (all-gathered) to arrive at the same bands."""
+    out = [float(c) for c in row_costs]
+    tot_t = sum(float(t) for (r0, r1), t in zip(bands, times) if r1 > r0 and t > 0)
+    tot_c = sum(sum(out[r0:r1]) for (r0, r1), t in zip(bands, times) if r1 > r0 and t > 0)
+    if not (tot_t > 0 and tot_c > 0):
+        return out
+    for (r0, r1), t in zip(bands, times):
+        c = sum(out[r0:r1])
+        if r1 > r0 and t > 0 and c > 0:
+            f = (float(t) / tot_t) / (c / tot_c)
+            for r in range(r0, r1):
+                out[r] *= f
+    return out
 
 
 def gather_bands(dist, buf, height, world, rank, bands=None):

@@ -46,6 +46,14 @@ def main():
     if len(sys.argv) > 4 and sys.argv[4] == "weighted":          # cost-balanced bands from a pilot (the oracle's ray counts per tile row)
         costs = [float(osc.render(1, G.RNG_SAMPLE, rows=(t * 16, min(H, t * 16 + 16)), threads=2)[1].rays) for t in range((H + 15) // 16)]
         bands = sharding.bands_weighted(H, world, costs)
+    if len(sys.argv) > 4 and sys.argv[4] == "feedback":          # what bench.py does by default: cuts at any row, corrected by (here: made-up) band times
+        costs = [float(osc.render(1, G.RNG_SAMPLE, rows=(t * 16, min(H, t * 16 + 16)), threads=2)[1].rays) for t in range((H + 15) // 16)]
+        bands = sharding.bands_weighted(H, world, costs, granularity=1)
+        mine = torch.tensor([1.0 + 0.37 * rank], dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rows = sharding.refine_row_costs(sharding.row_costs_from_tiles(H, costs), bands, [float(t.item()) for t in every])
+        bands = sharding.bands_from_row_costs(H, world, rows)
     pipe = sharding.ShardedGradPath(dist, world, rank, H, lambda: torch.zeros((H, W, 3), dtype=torch.float64),
                                     render_band, assemble, solve, bands=bands)
     pipe.step()

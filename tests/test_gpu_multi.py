@@ -163,12 +163,19 @@ def _bench(*extra):
 def test_bench_two_ranks_rehearsal_equals_one_rank(G):
     """`python bench.py --gpus 2` as typed (self-launching), both ranks on this box's one GPU over gloo: same strong-scaling
     image as the single-rank run, hash for hash."""
-    one = _bench("--plan-bands", "2")          # one rank, work items cut as for two bands: the image two ranks produce
-    two = _bench("--gpus", "2", "--dist-backend", "gloo")
+    one = _bench("--plan-bands", "2", "--bands", "cost")          # one rank, work items cut as for two bands: the image two ranks produce
+    two = _bench("--gpus", "2", "--dist-backend", "gloo", "--bands", "cost")    # (pilot bands: the same cuts run after run)
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and "rehearsal" in two and "rehearsal" not in one
+    assert two["band_feedback"] is None
     assert two["scaling"] == "weak" and two["config"]["workload"].count("8 spp total")
     assert one["scaling_strong"]["out_sha1"] == two["scaling_strong"]["out_sha1"]
     assert two["value"] > 0 and two["exchange_ms"] > 0
+    # the default: the pilot's bands corrected twice by the ranks' own render times during the warm-up (the cuts then depend on the
+    # clock, the image on the cuts only through the work-item plan): every round's bands cover the film, the figures are there
+    fb = _bench("--gpus", "2", "--dist-backend", "gloo")
+    assert fb["band_feedback"]["rounds"] == 2 and len(fb["band_feedback"]["rows"]) == 3 and len(fb["band_feedback"]["render_ms_per_rank"]) == 2
+    assert all(sum(rows) == 512 and len(rows) == 2 for rows in fb["band_feedback"]["rows"]) and all(t > 0 for ts in fb["band_feedback"]["render_ms_per_rank"] for t in ts)
+    assert fb["value"] > 0 and "time feedback" in fb["config"]["sharding"]
     # and N=2 over RCCL on a one-GPU node is refused with a message, not a line
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300)
     import torch

@@ -30,12 +30,23 @@ for name, size, spp in (("C2' cbox 512x512x256", 512, 256), ("C3 cbox 1024x1024x
     pilot = sc.tile_row_costs()
     print("   pilot (rays per tile row at 1 spp, relative to the mean): " + " ".join(f"{c / (sum(pilot) / len(pilot)):.2f}" for c in pilot), flush=True)
     for n in (2, 4, 8):
-        for label, bands in (("equal tile rows", sharding.all_bands(size, n)), ("equal pilot cost", sharding.bands_weighted(size, n, pilot))):
+        k = n if weak else 1                       # weak scaling: 16 spp per GPU = 16 N spp on the band
+
+        def run(label, bands, with_film_plan=False):
             plan = max(b[1] - b[0] for b in bands)
-            k = n if weak else 1                       # weak scaling: 16 spp per GPU = 16 N spp on the band
             ms = [cost(b, plan, spp * k) for b in bands]
-            film_plan = [cost(b, 0, spp * k) for b in bands[:1]][0] if label == "equal tile rows" else None
+            film_plan = [cost(b, 0, spp * k) for b in bands[:1]][0] if with_film_plan else None
             mean = sum(ms) / n
-            print(f"   N={n} {label:16s} rows " + " ".join(str(b[1] - b[0]) for b in bands) + ": " + " ".join(f"{m:.2f}" for m in ms) +
+            print(f"   N={n} {label:34s} rows " + " ".join(str(b[1] - b[0]) for b in bands) + ": " + " ".join(f"{m:.2f}" for m in ms) +
                   f" ms | max/mean {max(ms) / mean:.3f} | efficiency of the render (one-GPU time / ({'1' if weak else 'N'} x slowest band)) {whole / ((1 if weak else n) * max(ms)):.3f}" +
                   (f" | band 0 with the work items cut for the whole film (round 2): {film_plan:.2f} ms" if film_plan else ""), flush=True)
+            return ms
+        run("equal tile rows", sharding.all_bands(size, n), True)
+        run("equal pilot cost, whole tile rows", sharding.bands_weighted(size, n, pilot, granularity=16))
+        bands = sharding.bands_weighted(size, n, pilot, granularity=1)
+        ms = run("equal pilot cost, any row", bands)
+        rows = sharding.row_costs_from_tiles(size, pilot)
+        for it in (1, 2):                              # what bench.py does during its warm-up steps: the frame's own clock corrects the pilot
+            rows = sharding.refine_row_costs(rows, bands, ms)
+            bands = sharding.bands_from_row_costs(size, n, rows)
+            ms = run(f"after {it} round(s) of time feedback", bands)
