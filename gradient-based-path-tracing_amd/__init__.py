@@ -76,6 +76,8 @@ def lib():
         L.gdpt_band_rows_weighted.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.gdpt_tile_row_costs.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.c_int]
         L.gdpt_poisson_forget_stream.argtypes = [vp]
+        L.gdpt_band_rows_from_row_costs.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.gdpt_multi_rebalance.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
         L.gdpt_multi_create.argtypes = [C.POINTER(defs.GdptSceneDesc), C.POINTER(defs.GdptMultiConfig), C.POINTER(vp)]
         L.gdpt_multi_free.argtypes = [vp]
         L.gdpt_multi_free.restype = None
@@ -264,6 +266,17 @@ def band_rows_weighted(height, num_bands, band, costs):
     return r0.value, r1.value
 
 
+def band_rows_from_row_costs(height, num_bands, band, row_costs, granularity=1):
+    """Rows [r0, r1) of one band of a sharding balanced on per-row costs, as the C host computes them (gdpt_band_rows_from_row_costs;
+    mirror: sharding.bands_from_row_costs)."""
+    r0, r1 = C.c_int32(), C.c_int32()
+    arr = (C.c_double * len(row_costs))(*[float(c) for c in row_costs])
+    if len(row_costs) != int(height):
+        raise ValueError("one cost per pixel row expected")
+    _check(lib().gdpt_band_rows_from_row_costs(int(height), int(num_bands), int(band), arr, int(granularity), C.byref(r0), C.byref(r1)))
+    return r0.value, r1.value
+
+
 class MultiScene:
     """The scene uploaded to several devices of one node, tile loop sharded into row bands (include/gdpt.h,
     gdpt_multi_*): replaces the reference's thread pool over tiles (src/parallel.cpp:183-256)."""
@@ -289,6 +302,12 @@ class MultiScene:
                                                      _dp(bufs["img"]), _dp(bufs["cx0"]), _dp(bufs["cy0"]), _dp(bufs["cx1"]), _dp(bufs["cy1"]),
                                                      C.byref(rs), C.byref(ms)))
         return (out, bufs, rs, ms) if return_buffers else out
+
+    def rebalance(self, band_ms, granularity=1):
+        """Feedback between frames (gdpt_multi_rebalance): `band_ms` = GdptMultiStats.render_ms of the last call; the bands are cut
+        again on the corrected cost model, at multiples of `granularity` rows."""
+        arr = (C.c_double * len(band_ms))(*[float(t) for t in band_ms])
+        _check(lib().gdpt_multi_rebalance(self.handle, arr, int(granularity)))
 
     def close(self):
         if getattr(self, "handle", None):

@@ -89,6 +89,62 @@ void band_rows_weighted(int height, int n, const double *cost, int tile_rows, st
     for (int k = used + 1; k <= n; k++) (*first_tile)[(size_t)k] = T;
 }
 
+// The same linear partition on per-row costs, cuts on multiples of `gran` rows (gran divides 16); first_row gets n + 1 entries.
+// Mirror: sharding.bands_from_row_costs (units summed row by row, prefix sums unit by unit, first minimum wins).
+void bands_from_row_costs(int height, int n, const double *row_cost, int gran, std::vector<int> *first_row) {
+    if (gran < 1 || kTile % gran != 0) throw std::runtime_error("bands_from_row_costs: granularity must divide the tile height");
+    const int U = (height + gran - 1) / gran;
+    std::vector<double> pre((size_t)U + 1, 0.0);
+    for (int u = 0; u < U; u++) {
+        double c = 0.0;
+        for (int r = u * gran; r < std::min(height, u * gran + gran); r++) {
+            if (!(row_cost[r] >= 0.0)) throw std::runtime_error("bands_from_row_costs: negative or non-finite cost");
+            c += row_cost[r];
+        }
+        pre[(size_t)u + 1] = pre[(size_t)u] + c;
+    }
+    const int used = std::min(n, U);
+    const double inf = 1e300;
+    std::vector<std::vector<double>> best((size_t)used + 1, std::vector<double>((size_t)U + 1, inf));
+    std::vector<std::vector<int>> cut((size_t)used + 1, std::vector<int>((size_t)U + 1, 0));
+    best[0][0] = 0.0;
+    for (int k = 1; k <= used; k++)
+        for (int t = k; t <= U - (used - k); t++)
+            for (int s = k - 1; s < t; s++) {
+                if (best[(size_t)k - 1][(size_t)s] >= inf) continue;
+                const double v = std::max(best[(size_t)k - 1][(size_t)s], pre[(size_t)t] - pre[(size_t)s]);
+                if (v < best[(size_t)k][(size_t)t]) { best[(size_t)k][(size_t)t] = v; cut[(size_t)k][(size_t)t] = s; }
+            }
+    std::vector<int> first((size_t)n + 1, U);
+    int t = U;
+    for (int k = used; k >= 1; k--) { first[(size_t)k] = t; t = cut[(size_t)k][(size_t)t]; }
+    first[0] = 0;
+    first_row->resize((size_t)n + 1);
+    for (int k = 0; k <= n; k++) (*first_row)[(size_t)k] = std::min(first[(size_t)k] * gran, height);
+}
+
+// Feedback from measured band times: every band's rows rescaled so that its modelled share equals its measured share
+// (sharding.refine_row_costs, operation for operation). Bands without rows, time or modelled cost keep their rows' costs.
+void refine_row_costs(std::vector<double> &row_cost, const std::vector<std::pair<int, int>> &bands, const double *ms) {
+    double tot_t = 0.0, tot_c = 0.0;
+    for (size_t b = 0; b < bands.size(); b++) {
+        if (!(bands[b].second > bands[b].first) || !(ms[b] > 0)) continue;
+        tot_t += ms[b];
+        double c = 0.0;
+        for (int r = bands[b].first; r < bands[b].second; r++) c += row_cost[(size_t)r];
+        tot_c += c;
+    }
+    if (!(tot_t > 0 && tot_c > 0)) return;
+    for (size_t b = 0; b < bands.size(); b++) {
+        double c = 0.0;
+        for (int r = bands[b].first; r < bands[b].second; r++) c += row_cost[(size_t)r];
+        if (bands[b].second > bands[b].first && ms[b] > 0 && c > 0) {
+            const double f = (ms[b] / tot_t) / (c / tot_c);
+            for (int r = bands[b].first; r < bands[b].second; r++) row_cost[(size_t)r] *= f;
+        }
+    }
+}
+
 // Reusable barrier for the per-device host threads of one call (C++17: no std::barrier). Every arrival carries the
 // rank's own verdict ("I have failed"); the verdict of the ROUND — has anyone? — is formed under the barrier's lock by the
 // last arriver and handed to every participant, so all ranks take the same branch behind it. (Reading the other ranks'
@@ -129,6 +185,7 @@ struct GdptMulti {
     int n = 0, w = 0, h = 0, exchange = GDPT_EXCHANGE_RCCL, scene_spp = 0;
     bool equal_bands = false;
     int plan_rows = 0;             // rows of the largest band: GdptRenderParams::plan_rows of every band's render
+    std::vector<double> row_cost;  // cost model of the film's rows (uniform, the pilot's, or corrected by gdpt_multi_rebalance)
     bool comms_aborted = false;    // a failure behind the first collective tore the communicators down: the handle is spent
     std::vector<Rank> ranks;
     // one host thread per device 1..n-1, started once and parked between calls (device 0 is driven by the caller, as
@@ -376,6 +433,11 @@ int gdpt_multi_create(const GdptSceneDesc *desc, const GdptMultiConfig *cfg, Gdp
                 std::vector<double> cost((size_t)T);
                 if (gdpt_tile_row_costs(r.scene.get(), 1, cost.data(), T) != 0) throw std::runtime_error(std::string("gdpt_multi_create: pilot render: ") + gdpt_last_error());
                 band_rows_weighted(m->h, n, cost.data(), T, &first_tile);
+                m->row_cost.resize((size_t)m->h);                  // a tile row's cost spread over its rows (sharding.row_costs_from_tiles)
+                for (int t = 0; t < T; t++) {
+                    const int r0 = t * kTile, r1 = std::min(m->h, r0 + kTile);
+                    for (int rr = r0; rr < r1; rr++) m->row_cost[(size_t)rr] = cost[(size_t)t] / (double)(r1 - r0);
+                }
                 r.row_begin = 0; r.row_end = std::min(first_tile[1] * kTile, m->h);
             }
             ck(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking), "hipStreamCreate");
@@ -386,6 +448,7 @@ int gdpt_multi_create(const GdptSceneDesc *desc, const GdptMultiConfig *cfg, Gdp
         }
         m->equal_bands = equal;
         for (const Rank &r : m->ranks) m->plan_rows = std::max(m->plan_rows, r.row_end - r.row_begin);
+        if (m->row_cost.empty()) m->row_cost.assign((size_t)m->h, 1.0);
         if (cfg->exchange == GDPT_EXCHANGE_PEER_COPY) {
             for (int i = 0; i < n; i++)
                 for (int j = 0; j < n; j++) {
@@ -406,6 +469,38 @@ int gdpt_multi_create(const GdptSceneDesc *desc, const GdptMultiConfig *cfg, Gdp
         }
         m->start_workers();
         *out = m.release();
+    });
+}
+
+int gdpt_band_rows_from_row_costs(int height, int num_bands, int band, const double *row_cost, int granularity_rows, int32_t *row_begin, int32_t *row_end) {
+    return gdpt::guarded([&]() {
+        if (height <= 0 || num_bands <= 0 || band < 0 || band >= num_bands || !row_begin || !row_end || !row_cost) throw std::runtime_error("gdpt_band_rows_from_row_costs: bad argument");
+        std::vector<int> first;
+        bands_from_row_costs(height, num_bands, row_cost, granularity_rows, &first);
+        *row_begin = first[(size_t)band]; *row_end = first[(size_t)band + 1];
+    });
+}
+
+int gdpt_multi_rebalance(GdptMulti *m, const double *band_ms, int granularity_rows) {
+    return gdpt::guarded([&]() {
+        if (!m || !band_ms) throw std::runtime_error("gdpt_multi_rebalance: null argument");
+        for (int i = 0; i < m->n; i++) if (!(band_ms[i] >= 0.0)) throw std::runtime_error("gdpt_multi_rebalance: negative or non-finite time");
+        std::vector<std::pair<int, int>> bands;
+        for (const Rank &r : m->ranks) bands.push_back({r.row_begin, r.row_end});
+        std::vector<double> model = m->row_cost;
+        refine_row_costs(model, bands, band_ms);
+        std::vector<int> first;
+        bands_from_row_costs(m->h, m->n, model.data(), granularity_rows, &first);      // (throws before anything is changed)
+        m->row_cost.swap(model);
+        bool equal = true;
+        m->plan_rows = 0;
+        for (int i = 0; i < m->n; i++) {
+            Rank &r = m->ranks[(size_t)i];
+            r.row_begin = first[(size_t)i]; r.row_end = first[(size_t)i + 1];
+            if (r.row_end - r.row_begin != first[1] - first[0] || r.row_end <= r.row_begin) equal = false;
+            m->plan_rows = std::max(m->plan_rows, r.row_end - r.row_begin);
+        }
+        m->equal_bands = equal;
     });
 }
 

@@ -336,7 +336,18 @@ int gdpt_band_rows_weighted(int height, int num_bands, int band, const double *t
  * pixel (GDPT_RNG_SAMPLE, reference shift). Exact counts, so every caller — every rank of a sharded run — gets the same
  * numbers. `capacity` >= ceil(height / 16). Blocking; what the multi-device hosts balance their bands by. */
 int gdpt_tile_row_costs(GdptScene *scene, int spp, double *cost, int capacity);
+/* The same partition on a cost per pixel ROW (`row_cost[height]`), cuts on multiples of `granularity_rows` (1, 2, 4, 8 or 16): the
+ * persistent kernels anchor their 16x16 work items at a band's first row, so a band of the GDPT_RNG_SAMPLE streams need not consist
+ * of whole tile rows (GDPT_RNG_TILE does: granularity 16). Host only. */
+int gdpt_band_rows_from_row_costs(int height, int num_bands, int band, const double *row_cost, int granularity_rows,
+                                  int32_t *row_begin, int32_t *row_end);
 int gdpt_multi_create(const GdptSceneDesc *desc, const GdptMultiConfig *config, GdptMulti **out);
+/* Feedback between frames: `band_ms[i]` = measured render time of band i in the last call (GdptMultiStats.render_ms). The handle
+ * keeps a cost model of the film's rows (uniform, or the pilot's with config.balance); every band's rows are rescaled so that the
+ * band's modelled share equals its measured share, and the bands are cut again, on multiples of `granularity_rows`. Call between
+ * two renders, from the thread that renders. The images of later calls differ from earlier ones in the last bits of their sums
+ * (the work items follow the largest band, GdptRenderParams.plan_rows); GDPT_RNG_TILE renders need granularity 16. */
+int gdpt_multi_rebalance(GdptMulti *multi, const double *band_ms, int granularity_rows);
 void gdpt_multi_free(GdptMulti *multi);
 /* Whole Integrator::GradPath on the device set; arguments as gdpt_gradient_path_render (params->row_begin/row_end
  * must be 0: the library chooses the bands). Blocking. */

@@ -60,6 +60,67 @@ def test_cost_balanced_bands_of_the_c_host_equal_the_python_mirror(G):
     assert sharding.bands_weighted(512, 8, [1.0] * 32) == sharding.all_bands(512, 8)
 
 
+def test_row_cost_bands_of_the_c_host_equal_the_python_mirror(G):
+    """gdpt_band_rows_from_row_costs and sharding.bands_from_row_costs: the same cuts at every granularity, optimal by brute force
+    on small cases."""
+    import itertools
+    from gdpt_amd import sharding
+    rng = np.random.default_rng(11)
+    for height in (1, 3, 16, 37, 64, 130, 512):
+        for costs in (np.ones(height), rng.uniform(0.2, 3.0, height), np.concatenate([np.full(height // 2, 1.0), np.full(height - height // 2, 2.5)]), np.zeros(height)):
+            for n in (1, 2, 3, 8):
+                for g in (1, 4, 16):
+                    bands = [G.band_rows_from_row_costs(height, n, b, list(costs), g) for b in range(n)]
+                    assert bands == sharding.bands_from_row_costs(height, n, list(costs), g), (height, n, g)
+                    assert bands[0][0] == 0 and bands[-1][1] == height and all(a[1] == b[0] for a, b in zip(bands, bands[1:]))
+                    assert all(b[0] % g == 0 or b[0] == height for b in bands)
+                    if height <= 12 and g == 1:
+                        k = min(n, height)
+                        worst = max(costs[a:b].sum() for a, b in bands if b > a)
+                        for cuts in itertools.combinations(range(1, height), k - 1):
+                            edges = (0,) + cuts + (height,)
+                            assert max(costs[a:b].sum() for a, b in zip(edges, edges[1:])) >= worst - 1e-12
+    with pytest.raises(G.GdptError):
+        G.band_rows_from_row_costs(64, 2, 0, [1.0] * 64, 5)
+
+
+@pytest.mark.gpu
+def test_device_set_rebalanced_by_band_times(G, scene_tmp):
+    """gdpt_multi_rebalance: measured band times correct the handle's cost model and the bands are cut again at any row; the
+    images of the next call equal the single-device images with the new work-item plan, and the cuts are the Python mirror's
+    (what bench.py's ranks compute from the all-gathered times)."""
+    from gdpt_amd import sharding
+    xml = scene_variant(scene_tmp, "cbox/cbox_gdpt.xml", width=64, height=128)
+    sd = G.parse_scene(xml)
+    one = G.Scene(sd)
+    for balance in (False, True):
+        ms = G.MultiScene(sd, (0, 0, 0), exchange=G.EXCHANGE_PEER_COPY, balance=balance)
+        _, _, _, st = ms.gradient_path_render(5, G.RNG_SAMPLE, return_buffers=True)
+        bands = [(st.row_begin[i], st.row_end[i]) for i in range(3)]
+        model = sharding.row_costs_from_tiles(128, one.tile_row_costs()) if balance else [1.0] * 128
+        times = [1.0, 2.0, 1.5]                                  # as if the middle band had taken twice as long as the first
+        ms.rebalance(times, granularity=1)
+        model = sharding.refine_row_costs(model, bands, times)
+        want_bands = sharding.bands_from_row_costs(128, 3, model)
+        out, bufs, rs, st2 = ms.gradient_path_render(5, G.RNG_SAMPLE, return_buffers=True)
+        got = [(st2.row_begin[i], st2.row_end[i]) for i in range(3)]
+        assert got == want_bands and got != bands and got[1][1] - got[1][0] < bands[1][1] - bands[1][0]
+        assert any(b[0] % 16 for b in got[1:])                   # cuts at rows that are no tile boundaries
+        want_out, want, wrs, _ = one.gradient_path_render(5, G.RNG_SAMPLE, return_buffers=True, plan_rows=max(b[1] - b[0] for b in got))
+        assert np.array_equal(out, want_out)
+        for k in BUFS:
+            assert np.array_equal(bufs[k], want[k]), k
+        assert rs.rays == wrs.rays
+        # a second round with the real clock of the call just made: still a partition of the film
+        ms.rebalance([st2.render_ms[i] for i in range(3)], granularity=16)
+        _, _, _, st3 = ms.gradient_path_render(5, G.RNG_SAMPLE, return_buffers=True)
+        again = [(st3.row_begin[i], st3.row_end[i]) for i in range(3)]
+        assert again[0][0] == 0 and again[-1][1] == 128 and all(a[1] == b[0] and a[0] % 16 == 0 for a, b in zip(again, again[1:]))
+        with pytest.raises(G.GdptError):
+            ms.rebalance([1.0, -1.0, 1.0])
+        ms.close()
+
+
 @pytest.mark.gpu
 def test_cost_balanced_device_set(G, scene_tmp):
     """GdptMultiConfig.balance: the bands come from a pilot render's ray counts (gdpt_tile_row_costs) and
