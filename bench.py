@@ -516,16 +516,24 @@ def _find(table, name):
 def _num_chunks(spp, pixels, lanes=256 * 2 * 256):
     """Work items per pixel of the persistent render kernel (make_chunk_plan, csrc/hip/render_kernels.hip)."""
     cap = max(1, spp * pixels // (lanes * 4))
-    if spp > cap * 56:                       # never more than 64 chunks
-        cap = (spp + 55) // 56
-    rem, n = spp, 0
+    q = min(8, (4 * lanes + pixels - 1) // pixels) if 4 * lanes > pixels > 0 else 1
+    if spp <= q:
+        q = 1
+    slots = 64 // q
+    head = (slots - 4 if slots > 4 else 1) if q > 1 else 56
+    v = (spp + q - 1) // q
+    if v > cap * head:
+        cap = (v + head - 1) // head
+    rem, sizes = v, []
     while rem > 0:
         sz = 1 if rem <= 2 else min(max(1, (rem * 11 + 19) // 20), cap)
-        if n == 63:
+        if len(sizes) == slots - 1:
             sz = rem
         rem -= sz
-        n += 1
-    return n
+        sizes.append(sz)
+    n, excess = len(sizes) * q, q * v - spp
+    excess -= min(excess, sum(q for s_ in sizes if s_ > 1))
+    return n - excess
 
 
 def _kernel_lines(got, W, H, spp, pmc):

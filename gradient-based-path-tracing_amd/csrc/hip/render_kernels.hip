@@ -1,6 +1,7 @@
 // render_kernels.hip — launch dispatch of the GDPT render kernels (device code: render_device.h).
 #include "render_wavefront.h"
 
+#include "../capi_common.h"
 #include <stdexcept>
 #include <string>
 
@@ -243,9 +244,10 @@ unsigned persistent_blocks(const RenderLaunch &rl, long long num_items) {
 // launch on cbox 512x512x16 (tests/prof_drain.py; bounding the path length barely changed it, so it is the ITEM, not the
 // longest path). Chunks therefore shrink along the queue — each takes about 55 % of the samples still unassigned, the
 // last ones are single samples — and the queue hands out chunk 0 of every pixel, then chunk 1, ...: long items start
-// early, the tail of the launch consists of one-sample items. 16 spp on a 512^2 film -> 8,5,2,1 (as many partial
-// records as the four equal chunks before); 64 -> 32,18,8,3,2,1; 256 -> 128,71,32,14,6,3,1,1. Small bands with many samples (multi-GPU row bands) cap the chunk size so that every resident lane still sees
-// several items. One 128-byte partial record per item; gdpt_reduce_partials merges a pixel's records in chunk order,
+// early, the tail of the launch consists of one-sample items. The rule is applied per ROUND of items, not per chunk (below):
+// 16 spp on a 512^2 film -> 5,5,2,2,1,1 (8,5,2,1 until round 3); 64 -> 18,18,8,8,3,3,2,2,1,1; a 64-row band of that film at 128 spp
+// -> 8 x 8, 5 x 8, 2 x 8, 1 x 8. Small bands with many samples (multi-GPU row bands) cap the chunk size so that every resident lane
+// still sees several items. One 128-byte partial record per item; gdpt_reduce_partials merges a pixel's records in chunk order,
 // so the result depends neither on which lane ran what nor on when.
 ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long lanes) {
     ChunkPlan p{};
@@ -260,19 +262,46 @@ ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long 
     // at least ~4 items per resident lane, as far as the sample count allows
     long long cap = (long long)spp * pixels / (lanes > 0 ? lanes * 4 : 1);
     if (cap < 1) cap = 1;
-    if ((long long)spp > cap * (kMaxChunks - 8)) cap = ((long long)spp + kMaxChunks - 9) / (kMaxChunks - 8);   // never more than kMaxChunks chunks
-    int rem = spp, n = 0;
-    p.begin[0] = 0;
+    // The queue is chunk-major, so one ROUND of items — one per resident lane — spans lanes / pixels chunks. What is in flight when the
+    // queue runs dry is the last round and the stragglers of the ones before it, so the sizes have to fall off per ROUND, not per
+    // chunk: a 64-row band of the 512x512 film at 128 spp (pixels = lanes / 4) with the tail "..., 8, 5, 2, 1" had 8-, 5-, 2- and
+    // 1-sample items in its last round together — queue dry after 1.95 ms, then 1.0 ms of drain, against 0.39 ms for the whole film at
+    // 16 spp (profiles/r03_prof_band.txt). The plan is therefore made for spp / q samples and every chunk of it is laid down q times,
+    // q = ceil(rounds * lanes / pixels): every size of the shrinking tail then lasts `rounds` rounds. rounds = 4 (measured: the band
+    // above 2.67 -> 2.23 ms, the speed of the whole film; the 512x512 film itself, q = 2: 16 spp -> 5,5,2,2,1,1 instead of 8,5,2,1,
+    // +1.3 % at 16 spp and +3 % at 256 spp, profiles/r03_ab_plan_rounds.txt; 6 and 8 rounds no better).
+    const long long rounds = std::min(8, std::max(1, gdpt::debug_knob_int("plan_rounds", 4)));
+    long long q = (pixels > 0 && rounds * lanes > pixels) ? (rounds * lanes + pixels - 1) / pixels : 1;
+    if (q > 8) q = 8;
+    if ((long long)spp <= q) q = 1;                             // (nothing to shape: the rule below makes single samples)
+    const long long slots = kMaxChunks / q;                     // chunks the virtual plan may have (q = 1: kMaxChunks)
+    const long long head = q > 1 ? (slots > 4 ? slots - 4 : 1) : kMaxChunks - 8;      // of which for cap-sized chunks (the rest: the shrinking tail)
+    const int v = (int)(((long long)spp + q - 1) / q);          // samples of the virtual plan; q * v - spp < q are taken back below
+    if ((long long)v > cap * head) cap = ((long long)v + head - 1) / head;             // never more than kMaxChunks chunks
+    int sizes[kMaxChunks];
+    int rem = v, m = 0;
     while (rem > 0) {
         long long sz = ((long long)rem * 11 + 19) / 20;        // ceil(0.55 * rem)
         if (rem <= 2) sz = 1;                                  // the tail of the queue: single samples
         if (sz > cap) sz = cap;
         if (sz < 1) sz = 1;
-        if (n == kMaxChunks - 1) sz = rem;
+        if (m == (int)slots - 1) sz = rem;
         rem -= (int)sz;
-        p.begin[n + 1] = p.begin[n] + (int)sz;
-        n++;
+        sizes[m++] = (int)sz;
     }
+    int excess = (int)(q * v - spp);                            // < q <= 8: taken from the first (largest) chunks, one sample each
+    int n = 0;
+    p.begin[0] = 0;
+    for (int c = 0; c < m; c++)
+        for (int r = 0; r < (int)q; r++) {
+            int sz = sizes[c];
+            if (excess > 0 && sz > 1) { sz--; excess--; }
+            p.begin[n + 1] = p.begin[n] + sz;
+            n++;
+        }
+    // (excess left over only if every chunk was a single sample: drop chunks from the end)
+    while (excess > 0 && n > 1) { n--; excess--; }
+    p.begin[n] = spp;
     p.n = n;
     return p;
 }
