@@ -531,9 +531,7 @@ def _num_chunks(spp, pixels, lanes=256 * 2 * 256):
             sz = rem
         rem -= sz
         sizes.append(sz)
-    n, excess = len(sizes) * q, q * v - spp
-    excess -= min(excess, sum(q for s_ in sizes if s_ > 1))
-    return n - excess
+    return len(sizes) * q - (0 if any(s_ > 1 for s_ in sizes) else q * v - spp)
 
 
 def _kernel_lines(got, W, H, spp, pmc):

@@ -289,19 +289,19 @@ ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long 
         rem -= (int)sz;
         sizes[m++] = (int)sz;
     }
-    int excess = (int)(q * v - spp);                            // < q <= 8: taken from the first (largest) chunks, one sample each
+    int excess = (int)(q * v - spp);                            // < q <= 8 samples too many: the last copies of the smallest size above 1 give
+    int shrink = -1;                                            // one back each (the sizes stay in descending order); all single: chunks dropped
+    for (int c = 0; c < m; c++) if (sizes[c] > 1) shrink = c;
     int n = 0;
     p.begin[0] = 0;
     for (int c = 0; c < m; c++)
         for (int r = 0; r < (int)q; r++) {
             int sz = sizes[c];
-            if (excess > 0 && sz > 1) { sz--; excess--; }
+            if (c == shrink && r >= (int)q - excess) sz--;
             p.begin[n + 1] = p.begin[n] + sz;
             n++;
         }
-    // (excess left over only if every chunk was a single sample: drop chunks from the end)
-    while (excess > 0 && n > 1) { n--; excess--; }
-    p.begin[n] = spp;
+    if (shrink < 0) n -= excess;                                // (every chunk a single sample: q * v - spp of them too many)
     p.n = n;
     return p;
 }

@@ -110,10 +110,14 @@ def test_work_item_plan_invariants(G):
             assert sizes == sorted(sizes, reverse=True), (spp, pixels, sizes)          # long items first
             assert sizes[-1] == 1 or len(sizes) == 64, (spp, pixels, sizes)            # the queue ends in single samples
             assert len(sizes) == bench._num_chunks(spp, pixels), (spp, pixels)          # bench.py's mirror (reduce-kernel byte model)
-    assert [b2 - b1 for b1, b2 in zip(*(lambda b: (b, b[1:]))(G.debug_knobs.chunk_plan(16, 512 * 512)))] == [8, 5, 2, 1]          # (first chunk capped at 8: at least four items per resident lane)
+    plan = lambda spp, px: [b2 - b1 for b1, b2 in zip(*(lambda b: (b, b[1:]))(G.debug_knobs.chunk_plan(spp, px)))]
+    assert plan(16, 512 * 512) == [5, 5, 2, 2, 1, 1]         # every size of the tail lasts four rounds of items: 512^2 pixels = 2 rounds per chunk
+    assert plan(16, 1024 * 1024) == [9, 4, 2, 1]             # 8 rounds per chunk: the 55 % rule as it is
+    assert plan(128, 512 * 64) == [8] * 8 + [5] * 8 + [2] * 8 + [1] * 8      # a 64-row band of the 512^2 film (one of eight ranks): a quarter round per chunk
+    assert plan(5, 512 * 512) == [2, 1, 1, 1] and plan(3, 64 * 64) == [1, 1, 1]
     # a 64-row band of a 1024 x 1024 x 256 spp render (8 GPUs) is cut like the whole film: the plan depends on the FILM, not the band
     assert G.debug_knobs.chunk_plan(256, 1024 * 1024) == G.debug_knobs.chunk_plan(256, 1024 * 1024)
     small = G.debug_knobs.chunk_plan(128, 64 * 64)                                     # few pixels, many samples: capped chunk size
-    assert max(b2 - b1 for b1, b2 in zip(small, small[1:])) <= max(1, 128 * 64 * 64 // (256 * 2 * 256 * 4), (128 + 55) // 56)   # (the 64-chunk limit wins here)
+    assert max(b2 - b1 for b1, b2 in zip(small, small[1:])) <= 4 and len(small) - 1 <= 64   # (the 64-chunk limit wins here: 8 copies of a plan of at most 8 chunks for 16 samples)
     eq = G.debug_knobs.chunk_plan(16, 512 * 512, force_log2k=2)
     assert eq == [0, 4, 8, 12, 16]
