@@ -304,6 +304,8 @@ void build_scene(const GdptSceneDesc *desc, int device, GdptScene *sc) {
         if (m.type == GDPT_MAT_ROUGHPLASTIC || m.type == GDPT_MAT_ROUGHDIELECTRIC) sc->has_rough = true;
         if (m.type == GDPT_MAT_DISNEY_GLASS || m.type == GDPT_MAT_DISNEY_BSDF || m.type == GDPT_MAT_ROUGHDIELECTRIC) sc->one_sided = false;   // two-sided lobes
     }
+    // scenes of {Lambertian, DisneyGlass}: paths through glass are long-tailed, the work items are cut smaller (render_kernels.hip: make_chunk_plan)
+    if ((sc->material_mask & (1u << GDPT_MAT_DISNEY_GLASS)) && (sc->material_mask & ~((1u << GDPT_MAT_LAMBERTIAN) | (1u << GDPT_MAT_DISNEY_GLASS))) == 0) sc->plan_take_pct = 40;
     // get_intersection_epsilon (src/scene.h:100-102) from Embree-style fp32 scene bounds (src/scene.cpp:29-33)
     double dx = (double)ub[0] - (double)lb[0], dy = (double)ub[1] - (double)lb[1], dz = (double)ub[2] - (double)lb[2];
     double radius = prims.empty() ? 0.0 : std::sqrt(dx * dx + dy * dy + dz * dz) / 2;
@@ -447,10 +449,11 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     rl.thresh_a = env_int("keep_frac", -1); rl.thresh_c = env_int("search_frac", -1);
     rl.force_log2k = env_int("log2k", -1);
     rl.num_cus = sc->num_cus;
+    rl.plan_take_pct = sc->plan_take_pct;
     rl.blocks_per_cu = env_int("blocks_per_cu", 0);
     rl.stamped = env_int("stamps", 0) != 0;
     {
-        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, b.plan_rows, b.spp, rl.force_log2k, (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256);
+        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, b.plan_rows, b.spp, rl.force_log2k, (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256, rl.plan_take_pct);
         if (need > sc->partials_doubles) {
             if (sc->d_partials) { ck(hipStreamSynchronize(stream), "hipStreamSynchronize"); hipFree(sc->d_partials); sc->d_partials = nullptr; }
             ck(hipMalloc((void **)&sc->d_partials, need * sizeof(double)), "hipMalloc(work-item partials)");
@@ -464,7 +467,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     if (rl.two_sided_machine) {
         const long long tiles = (long long)((sc->view.cam.width + 15) / 16) * ((b.row_end - b.row_begin + 15) / 16);
         const long long items = (tiles * 256) * gdpt::make_chunk_plan(b.spp, rl.force_log2k, (long long)sc->view.cam.width * b.plan_rows,
-                                                                      (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256).n;
+                                                                      (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256, rl.plan_take_pct).n;
         const size_t need = gdpt::twosided_log_bytes(gdpt::persistent_blocks(rl, items));
         if (need > sc->bounce_log_bytes) {
             if (sc->d_bounce_log) { ck(hipStreamSynchronize(stream), "hipStreamSynchronize"); hipFree(sc->d_bounce_log); sc->d_bounce_log = nullptr; }
@@ -479,7 +482,7 @@ void render_device_impl(GdptScene *sc, const GdptRenderParams *params, int scene
     if (rl.wavefront) {
         const long long tiles = (long long)((sc->view.cam.width + 15) / 16) * ((b.row_end - b.row_begin + 15) / 16);
         const long long items = (tiles * 256) * gdpt::make_chunk_plan(b.spp, rl.force_log2k, (long long)sc->view.cam.width * b.plan_rows,
-                                                                      (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256).n;
+                                                                      (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256, rl.plan_take_pct).n;
         int slots = gdpt::wf_slot_count(items);
         { const int forced = env_int("wf_slots", 0); if (forced > 0) slots = std::min(slots, (forced + 255) / 256 * 256); }   // tests: force slot reuse
         if (slots > sc->wf_slots) {
@@ -556,7 +559,7 @@ void path_render_device_impl(GdptScene *sc, const GdptRenderParams *params, doub
     rl.scene_fits_lds = !env_int("no_lds_scene", 0) &&
                         gdpt::scene_fits_lds_wide(sc->view.num_nodes4, sc->view.num_prims, sc->view.num_tris, sc->view.num_materials, sc->view.num_lights, sc->wide_stack_need);
     {
-        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, b.plan_rows, b.spp, rl.force_log2k, (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256);
+        size_t need = gdpt::render_partials_doubles(sc->view.cam.width, b.row_end - b.row_begin, b.plan_rows, b.spp, rl.force_log2k, (long long)rl.num_cus * (rl.blocks_per_cu > 0 ? rl.blocks_per_cu : 2) * 256, rl.plan_take_pct);
         if (need > sc->partials_doubles) {
             if (sc->d_partials) { ck(hipStreamSynchronize(stream), "hipStreamSynchronize"); hipFree(sc->d_partials); sc->d_partials = nullptr; }
             ck(hipMalloc((void **)&sc->d_partials, need * sizeof(double)), "hipMalloc(work-item partials)");

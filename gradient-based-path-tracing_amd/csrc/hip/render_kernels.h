@@ -55,6 +55,7 @@ struct RenderLaunch {
     int replay_per_step;           // two-sided lane machine (render_twosided.h), 0 = default
     bool no_spheres, const_textures;   // triangles only / every texture constant: kernels built without sphere / texture code
     bool stamped;                  // diagnostic build with in-kernel cycle stamps (test-only knob "stamps")
+    int plan_take_pct;             // work-item plan: share of the unassigned samples a chunk takes, percent (0 = default; scenes of long-tailed paths take less)
     double *partials;              // device, >= 15 * W * rows * 8 doubles (work-item partial sums)
     unsigned long long *queue_head;// device, work-queue head
 };
@@ -67,8 +68,8 @@ unsigned persistent_blocks(const RenderLaunch &rl, long long num_items);
 void launch_path_render(const DevSceneView &sv, const RenderLaunch &rl, hipStream_t stream);
 // Chunk sizes shrink along the queue (about 40 % of what is left each time, ending in single samples) unless
 // force_log2k >= 0 asks for 2^k equal chunks (tests). `lanes` = resident lanes of the persistent grid.
-ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long lanes);
-size_t render_partials_doubles(int width, int rows, int plan_rows, int spp, int force_log2k, long long lanes);
+ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long lanes, int take_pct = 0);    // take_pct: share of the unassigned samples a chunk takes (0 = the default 55)
+size_t render_partials_doubles(int width, int rows, int plan_rows, int spp, int force_log2k, long long lanes, int take_pct = 0);
 
 int wf_words();
 int wf_max_generations();

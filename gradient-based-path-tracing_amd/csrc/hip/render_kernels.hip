@@ -20,7 +20,7 @@ static long long resident_lanes(const RenderLaunch &rl) { return (long long)rl.n
 // 512x512x256 film, 1/8 of the work, then held 32 k items of 128 samples and took 9.3 ms instead of 3.8 —
 // profiles/r03_band_costs.txt.)
 static void set_chunks(gd::KernelArgs &a, const RenderLaunch &rl, int W, int rows) {
-    const ChunkPlan plan = make_chunk_plan(rl.spp, rl.force_log2k, (long long)W * rl.plan_rows, resident_lanes(rl));
+    const ChunkPlan plan = make_chunk_plan(rl.spp, rl.force_log2k, (long long)W * rl.plan_rows, resident_lanes(rl), rl.plan_take_pct);
     a.num_chunks = plan.n;
     for (int c = 0; c <= plan.n; c++) a.chunk_begin[c] = plan.begin[c];
     a.tiles_x = (W + 15) / 16;
@@ -249,7 +249,7 @@ unsigned persistent_blocks(const RenderLaunch &rl, long long num_items) {
 // -> 8 x 8, 5 x 8, 2 x 8, 1 x 8. Small bands with many samples (multi-GPU row bands) cap the chunk size so that every resident lane
 // still sees several items. One 128-byte partial record per item; gdpt_reduce_partials merges a pixel's records in chunk order,
 // so the result depends neither on which lane ran what nor on when.
-ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long lanes) {
+ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long lanes, int take_pct_arg) {
     ChunkPlan p{};
     if (spp < 1) spp = 1;
     if (force_log2k >= 0) {                                    // tests: 2^k equal chunks
@@ -270,7 +270,8 @@ ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long 
     // q = ceil(rounds * lanes / pixels): every size of the shrinking tail then lasts `rounds` rounds. rounds = 4 (measured: the band
     // above 2.67 -> 2.23 ms, the speed of the whole film; the 512x512 film itself, q = 2: 16 spp -> 5,5,2,2,1,1 instead of 8,5,2,1,
     // +1.3 % at 16 spp and +3 % at 256 spp, profiles/r03_ab_plan_rounds.txt; 6 and 8 rounds no better).
-    const long long rounds = std::min(8, std::max(1, gdpt::debug_knob_int("plan_rounds", 4)));
+    long long rounds = gdpt::debug_knob_int("plan_rounds", 4);
+    rounds = rounds <= 0 ? 4 : std::min(8LL, rounds);                                                    // (test knob; 0 = the default)
     long long q = (pixels > 0 && rounds * lanes > pixels) ? (rounds * lanes + pixels - 1) / pixels : 1;
     if (q > 8) q = 8;
     if ((long long)spp <= q) q = 1;                             // (nothing to shape: the rule below makes single samples)
@@ -278,10 +279,15 @@ ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long 
     const long long head = q > 1 ? (slots > 4 ? slots - 4 : 1) : kMaxChunks - 8;      // of which for cap-sized chunks (the rest: the shrinking tail)
     const int v = (int)(((long long)spp + q - 1) / q);          // samples of the virtual plan; q * v - spp < q are taken back below
     if ((long long)v > cap * head) cap = ((long long)v + head - 1) / head;             // never more than kMaxChunks chunks
+    // share of the unassigned samples a chunk takes, in percent: 55, or what the caller asks for (capi_device.hip: 40 for scenes whose
+    // paths are long-tailed — DisneyGlass: an item's time varies more, smaller items balance it, +9..15 %, profiles/r03_sweep_plan_twosided.txt)
+    long long take_pct = gdpt::debug_knob_int("plan_shrink", 0);                                         // (test knob; 0 = no override)
+    if (take_pct <= 0) take_pct = take_pct_arg > 0 ? take_pct_arg : 55;
+    take_pct = std::min(90LL, std::max(10LL, take_pct));
     int sizes[kMaxChunks];
     int rem = v, m = 0;
     while (rem > 0) {
-        long long sz = ((long long)rem * 11 + 19) / 20;        // ceil(0.55 * rem)
+        long long sz = ((long long)rem * take_pct + 99) / 100; // ceil(0.55 * rem)
         if (rem <= 2) sz = 1;                                  // the tail of the queue: single samples
         if (sz > cap) sz = cap;
         if (sz < 1) sz = 1;
@@ -306,9 +312,9 @@ ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long 
     return p;
 }
 
-size_t render_partials_doubles(int width, int rows, int plan_rows, int spp, int force_log2k, long long lanes) {
+size_t render_partials_doubles(int width, int rows, int plan_rows, int spp, int force_log2k, long long lanes, int take_pct) {
     const long long tiles = (long long)((width + 15) / 16) * ((rows + 15) / 16);
-    return (size_t)16 * (size_t)(tiles * 256) * (size_t)make_chunk_plan(spp, force_log2k, (long long)width * plan_rows, lanes).n;
+    return (size_t)16 * (size_t)(tiles * 256) * (size_t)make_chunk_plan(spp, force_log2k, (long long)width * plan_rows, lanes, take_pct).n;
 }
 
 bool scene_fits_lds(int num_nodes, int num_prims, int num_tris, int num_materials, int num_lights, int bvh_depth) {
