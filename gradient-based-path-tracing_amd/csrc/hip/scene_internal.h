@@ -27,7 +27,7 @@ struct GdptScene {
     int scene_spp = 0;             // <sampler sampleCount> of the description (default spp)
     bool one_sided = true, lambert_only = true;
     unsigned material_mask = 0;    // bit t = a material of type t is present
-    int plan_take_pct = 0;         // work-item plan: share of the unassigned samples a chunk takes (0 = default 55; 40 where DisneyGlass is the only non-Lambertian lobe)
+    int plan_take_pct = 0;         // work-item plan: share of the unassigned samples a chunk takes (0 = default 55; 40 where a refractive lobe is present)
     bool has_rough = false;        // RoughPlastic / RoughDielectric present: GradPath uses the evaluator built with those lobes
     std::vector<void *> allocations;
     // cached output/work buffers for the host-pointer entry points
