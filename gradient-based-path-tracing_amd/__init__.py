@@ -467,7 +467,7 @@ class debug_knobs:
         """GDPT_FORCE_EAGER=1 -> force_eager=1 ... for the manual sweep scripts (tests/sweep_*.py, tune_render.py)."""
         environ = os.environ if environ is None else environ
         names = ("force_eager", "log2k", "keep_frac", "search_frac", "blocks_per_cu", "no_lds_scene", "lds_wide",
-                 "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "sbvh", "sbvh_alpha", "plan_rounds", "plan_shrink", "bvh_collapse_dp", "stamps", "wavefront", "wf_slots", "wf_sort", "multi_fail_band", "multi_fail_stage", "dct_bk", "dct_bm", "full_material_switch", "no_plain_kernel", "replay_per_step")
+                 "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "sbvh", "sbvh_alpha", "plan_rounds", "plan_shrink", "plan_digits", "bvh_collapse_dp", "stamps", "wavefront", "wf_slots", "wf_sort", "multi_fail_band", "multi_fail_stage", "dct_bk", "dct_bm", "full_material_switch", "no_plain_kernel", "replay_per_step")
         lib().gdpt_debug_knobs_reset()
         for n in names:
             v = environ.get("GDPT_" + n.upper())

@@ -25,7 +25,7 @@ namespace {
 std::mutex g_knob_mu;
 std::map<std::string, double> g_knobs;     // test-only overrides, include/gdpt_debug.h
 const char *const kKnobNames[] = {"force_eager", "log2k", "keep_frac", "search_frac", "blocks_per_cu", "no_lds_scene", "lds_wide",
-                                  "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "sbvh", "sbvh_alpha", "plan_rounds", "plan_shrink", "bvh_collapse_dp", "stamps", "wavefront", "wf_slots", "wf_sort", "multi_fail_band", "multi_fail_stage", "dct_bk", "dct_bm", "full_material_switch", "no_plain_kernel", "replay_per_step"};
+                                  "no_twosided_machine", "presplit", "presplit_floor", "bvh_leaf_max", "bvh_leaf_factor", "sbvh", "sbvh_alpha", "plan_rounds", "plan_shrink", "plan_digits", "bvh_collapse_dp", "stamps", "wavefront", "wf_slots", "wf_sort", "multi_fail_band", "multi_fail_stage", "dct_bk", "dct_bm", "full_material_switch", "no_plain_kernel", "replay_per_step"};
 double g_stamps[16] = {0};
 } // namespace
 void debug_store_stamps(const unsigned long long *v, int n) {

@@ -259,6 +259,16 @@ ChunkPlan make_chunk_plan(int spp, int force_log2k, long long pixels, long long 
         for (int c = 0; c <= p.n; c++) p.begin[c] = (int)(((long long)c * spp) >> k);
         return p;
     }
+    {   // test knob plan_digits: the chunk sizes spelled out as decimal digits (552211 = 5,5,2,2,1,1), used if they add up to spp
+        long long digits = (long long)gdpt::debug_knob("plan_digits", 0.0);
+        int sz[18], m = 0, sum = 0;
+        for (; digits > 0 && m < 18; digits /= 10) { sz[m] = (int)(digits % 10); sum += sz[m]; if (sz[m] == 0) sum = -1000000; m++; }
+        if (m > 0 && sum == spp) {
+            p.n = m; p.begin[0] = 0;
+            for (int c = 0; c < m; c++) p.begin[c + 1] = p.begin[c] + sz[m - 1 - c];
+            return p;
+        }
+    }
     // at least ~4 items per resident lane, as far as the sample count allows
     long long cap = (long long)spp * pixels / (lanes > 0 ? lanes * 4 : 1);
     if (cap < 1) cap = 1;

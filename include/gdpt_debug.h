@@ -24,6 +24,7 @@
  *   sbvh                 (real) SAH builder with spatial splits: extra references allowed per primitive, 0 = object splits only (scene upload)
  *   plan_rounds          (1..8) work-item plan: rounds of items (one per resident lane) every size of the plan's shrinking tail lasts (default 4)
  *   plan_shrink          (10..90) work-item plan: percentage of the samples still unassigned that the next chunk takes (default 55)
+ *   plan_digits          (int) work-item plan spelled out: decimal digits = chunk sizes (552211 = 5,5,2,2,1,1), used when they add up to the spp
  *   sbvh_alpha           (real) ... spatial splits are tried where the object split's children overlap by more than this fraction of the root's area
  *   wavefront            (0/1)  scenes walked from HBM, one-sided lobes: 1 = wavefront pipeline (step + trace kernels, path
  *                               state in HBM), 0 = lane machine; the two give bit-identical images
